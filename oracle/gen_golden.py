@@ -1,0 +1,298 @@
+"""Generate tests/golden/*.npz by importing the reference (skowae/NeRF) itself.
+
+Run only in the development container, where the reference checkout exists:
+
+    MPLBACKEND=Agg python oracle/gen_golden.py [/root/reference]
+
+The outputs are small input/output vectors of the reference's own functions
+(plus per-parameter checksums proving that seeded construction gives the same
+weights).  Nothing of the reference's source travels: only numbers.
+TEST INFRASTRUCTURE ONLY.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+sys.path.insert(0, os.path.join(REF, "src"))
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+from Camera import Camera, look_at_camera  # noqa: E402  (reference)
+from models.NeRF import NeRF  # noqa: E402
+from models.FastMLPNeRF import FastMLPNeRF  # noqa: E402
+from models.FastNGPNeRF import FastNGPNeRF  # noqa: E402
+from utils.positional_encoding import PositionalEncoding  # noqa: E402
+from utils.hash_grid_encoder import HashGridEncoder  # noqa: E402
+import utils.get_rays as legacy  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name), **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                                    for k, v in arrs.items()})
+    print("wrote", name, len(arrs), "arrays")
+
+
+def param_checksums(model):
+    return {k: np.array([float(v.double().sum()), float(v.double().abs().sum())])
+            for k, v in model.state_dict().items()}
+
+
+def sample_idx(n, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, n, (min(k, n),), generator=g)
+
+
+# ---------------------------------------------------------------- G1 ray generation
+def g1():
+    with open(os.path.join(REF, "src/data/skow/robot/transforms.json")) as f:
+        meta = json.load(f)
+    frames = meta["frames"]
+    poses = [torch.from_numpy(np.array(fr["transform_matrix"])).float() for fr in frames]
+    centers = torch.stack([p[:3, 3] for p in poses])
+    centre = centers.mean(0)
+    scale = 1.2 * (centers - centre).norm(dim=-1).max()
+    pose = poses[0].clone()
+    pose[:3, 3] = (pose[:3, 3] - centre) / scale
+    fr = frames[0]
+    W, H = 100, 75
+    sw, sh = W / fr["w"], H / fr["h"]
+    focal = (fr["fl_x"] * sw, fr["fl_y"] * sh)
+    pp = (fr["cx"] * sw, fr["cy"] * sh)
+    cam = Camera(eye=pose[:, 3], target=None, focal=focal, H=H, W=W, c2w=pose, pp=pp)
+    ro, rd = cam.get_rays()
+    out = dict(robot_c2w=pose[:3, :4].contiguous(), robot_intr=np.array([focal[0], focal[1], pp[0], pp[1]], dtype=np.float64),
+               robot_hw=np.array([H, W]), robot_o=ro.contiguous(), robot_d=rd)
+    # look-at camera (default principal point)
+    eye = torch.tensor([1.0, 1.0, 2.0])
+    tgt = torch.zeros(3)
+    cam = Camera(eye=eye, target=tgt, focal=(100.0, 100.0), H=100, W=100)
+    ro, rd = cam.get_rays()
+    out.update(look_c2w=cam.c2w, look_o=ro.contiguous(), look_d=rd,
+               look_up_z=look_at_camera(torch.tensor([0.0, 3.0, 0.0]), tgt))
+    # LLFF pose 0 (stored [3,5]: 3x4 pose + hwf column)
+    pb = np.load(os.path.join(REF, "src/data/llff/testscene/poses_bounds.npy"))
+    p0 = pb[0, :15].reshape(3, 5)
+    c2w = torch.from_numpy(p0[:, :4]).float()
+    f = float(p0[2, 4]) / 8.0
+    H, W = 378 // 6, 504 // 6
+    cam = Camera(eye=c2w[:, 3], target=None, focal=(f / 6, f / 6), H=H, W=W, c2w=c2w)
+    ro, rd = cam.get_rays()
+    out.update(llff_c2w=c2w, llff_f=np.array([f / 6]), llff_hw=np.array([H, W]), llff_o=ro.contiguous(), llff_d=rd,
+               llff_bounds=pb[0, 15:])
+    save("g1_raygen.npz", **out)
+    return out
+
+
+# ---------------------------------------------------------------- G2 stratified sampling
+def g2(g1o):
+    ro = g1o["look_o"][10:14, 20:28].contiguous()
+    rd = g1o["look_d"][10:14, 20:28].contiguous()
+    out = dict(rays_o=ro, rays_d=rd)
+    for tag, (near, far, n) in {"a": (2.0, 6.0, 64), "b": (0.05, 1.2, 64), "c": (0.25, 0.75, 17)}.items():
+        torch.manual_seed(1)
+        pts, z = Camera.sample_points_along_rays(ro, rd, near, far, n, perturb=True)
+        torch.manual_seed(1)
+        u = torch.rand_like(z)  # the same draw the call above made
+        pts0, z0 = Camera.sample_points_along_rays(ro, rd, near, far, n, perturb=False)
+        out.update({f"{tag}_cfg": np.array([near, far, n]), f"{tag}_u": u, f"{tag}_z": z, f"{tag}_pts": pts,
+                    f"{tag}_z0": z0.contiguous(), f"{tag}_pts0": pts0, f"{tag}_lin": torch.linspace(near, far, n)})
+    save("g2_stratified.npz", **out)
+    return out
+
+
+# ---------------------------------------------------------------- G3 positional encoding
+def g3():
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(64, 3, generator=g) * 12 - 6)
+    x[0] = 0.0
+    x[1] = torch.tensor([6.0, -6.0, 6.0])
+    x[2] = torch.tensor([1e-8, -1e-8, 3.14159265])
+    save("g3_pe.npz", x=x, pe10=PositionalEncoding(10)(x), pe4=PositionalEncoding(4)(x))
+
+
+# ---------------------------------------------------------------- G4 hash grid
+def fill_tables(enc):
+    """Closed-form table contents (level l, row r, feature f) so the far side
+    can rebuild them without shipping 41 MB."""
+    with torch.no_grad():
+        for l, emb in enumerate(enc.embeddings):
+            r = torch.arange(emb.weight.shape[0], dtype=torch.float64)
+            for f in range(2):
+                emb.weight[:, f] = (torch.sin(r * (0.37 + 0.011 * l) + 1.3 * f + 0.5 * l) * 0.5).float()
+
+
+def g4():
+    enc = HashGridEncoder()
+    fill_tables(enc)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(512, 3, generator=g) * 2 - 1
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2] = -1.0
+    x[3] = torch.tensor([0.5, -0.5, 0.25])        # exact cell boundaries on pow2 levels
+    x[4] = torch.tensor([-1e-7, 1e-7, -0.999999])
+    x[5] = torch.tensor([1.5, -2.25, 3.0])        # outside the unit cube
+    x[6] = torch.tensor([1.0 / 16, 3.0 / 32, -5.0 / 64])
+    x.requires_grad_(False)
+    feats = enc(x)
+    idx = []
+    wts = []
+    for emb, res in zip(enc.embeddings, enc.resolutions):
+        size = min(enc.hash_size, res ** 3)
+        pos = x.unsqueeze(1) * res
+        p0 = pos.floor().long()
+        w = pos - p0.float()
+        p1 = (p0 + 1) % res
+        p0 = p0 % res
+        lv = []
+        for bx in (0, 1):
+            for by in (0, 1):
+                for bz in (0, 1):
+                    c = torch.cat([(p1 if bx else p0)[..., 0:1], (p1 if by else p0)[..., 1:2],
+                                   (p1 if bz else p0)[..., 2:3]], dim=-1)
+                    lv.append(enc.hash_fn(c, size).squeeze(1))
+        idx.append(torch.stack(lv))
+        wts.append(w.squeeze(1))
+    idx = torch.stack(idx).to(torch.int32)  # [16,8,512]
+    # backward: d(sum(feats * a)) / d tables
+    a = torch.rand(512, 32, generator=g) - 0.5
+    (feats * a).sum().backward()
+    gsum = np.array([float(e.weight.grad.double().sum()) for e in enc.embeddings])
+    gl2 = np.array([float(e.weight.grad.double().norm()) for e in enc.embeddings])
+    rows = [sample_idx(e.weight.shape[0], 64, 40 + l) for l, e in enumerate(enc.embeddings)]
+    # sample rows that are actually touched: take them from the corner indices
+    rows = [idx[l].reshape(-1)[sample_idx(8 * 512, 64, 40 + l)].long() for l in range(16)]
+    grows = torch.stack([e.weight.grad[r] for e, r in zip(enc.embeddings, rows)])
+    save("g4_hash.npz", x=x, feats=feats.detach(), idx=idx, w=torch.stack(wts), a=a,
+         resolutions=np.array(enc.resolutions), sizes=np.array([e.weight.shape[0] for e in enc.embeddings]),
+         grad_sum=gsum, grad_l2=gl2, grad_rows=torch.stack(rows), grad_vals=grows)
+
+
+# ---------------------------------------------------------------- G5 models
+def model_case(name, model, x, d, g, boost=None):
+    if boost:
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                for pat, s in boost.items():
+                    if k.startswith(pat):
+                        p.mul_(s)
+    rgb, sigma = model(x, d)
+    a = torch.rand(rgb.shape, generator=g) - 0.5
+    b = torch.rand(sigma.shape, generator=g) - 0.5
+    loss = (rgb * a).sum() + (sigma * b).sum()
+    model.zero_grad()
+    loss.backward()
+    out = {f"{name}_rgb": rgb.detach(), f"{name}_sigma": sigma.detach(), f"{name}_a": a, f"{name}_b": b}
+    for k, p in model.named_parameters():
+        gr = p.grad.reshape(-1)
+        ii = sample_idx(gr.numel(), 64, 7)
+        out[f"{name}_gnorm/{k}"] = np.array([float(gr.double().norm())])
+        out[f"{name}_gidx/{k}"] = ii
+        out[f"{name}_gval/{k}"] = gr[ii]
+    return out
+
+
+def g5():
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(256, 3, generator=g) * 8 - 4
+    d = torch.randn(256, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    out = dict(x=x, d=d)
+    torch.manual_seed(0)
+    m = NeRF()
+    for k, v in param_checksums(m).items():
+        out[f"nerf_ck/{k}"] = v
+    out.update(model_case("nerf", m, x, d, g))
+    torch.manual_seed(0)
+    m = FastMLPNeRF()
+    for k, v in param_checksums(m).items():
+        out[f"fastmlp_ck/{k}"] = v
+    out.update(model_case("fastmlp", m, x, d, g))
+    save("g5_mlp.npz", **out)
+
+    xn = torch.rand(256, 3, generator=g) * 2 - 1
+    out = dict(x=xn, d=d * 1.7)  # un-normalised dirs: the model normalises them itself
+    torch.manual_seed(0)
+    m = FastNGPNeRF()
+    for k, v in param_checksums(m).items():
+        out[f"ngp_ck/{k}"] = v
+    out.update(model_case("ngp", m, xn, d * 1.7, g))
+    out["ngp_density"] = m.query_density(xn)
+    rgb0, sig0 = m(xn[:16], None)
+    out["ngp_nodir_rgb"] = rgb0.detach()
+    boost = {"hash_encoder": 1e3, "fc_density.0.weight": 1e4, "fc_density.2.weight": 3e3,
+             "fc_color.0.weight": 1e4, "fc_color.2.weight": 1e4, "skip_proj": 3.0}
+    out["boost_keys"] = np.array(list(boost.keys()))
+    out["boost_vals"] = np.array(list(boost.values()))
+    out.update(model_case("ngpb", m, xn, d * 1.7, g, boost=boost))
+    save("g5_ngp.npz", **out)
+
+
+# ---------------------------------------------------------------- G6 compositing
+def g6(g2o):
+    g = torch.Generator().manual_seed(6)
+    out = {}
+    for tag, n in (("a", 64), ("c", 17)):
+        z = g2o[f"{tag}_z"][:2, :4].contiguous()
+        rgb = torch.rand(2, 4, n, 3, generator=g)
+        sigma = torch.rand(2, 4, n, generator=g) * 3
+        sigma[0, 0, :] = 0.0
+        sigma[0, 1, 5] = 1e-6
+        sigma[0, 2, 7:] = 50.0
+        sigma[1, 0, -1] = 0.0
+        tgt = torch.rand(2, 4, 3, generator=g)
+        for wb in (False, True):
+            r = rgb.clone().requires_grad_(True)
+            s = sigma.clone().requires_grad_(True)
+            c, w = Camera.volume_render(r, s, z, white_bkgd=wb)
+            loss = torch.nn.functional.mse_loss(c, tgt) + 0.05 * (1 - w.sum(dim=-1)).abs().mean()
+            loss.backward()
+            k = f"{tag}{int(wb)}"
+            out.update({f"{k}_c": c.detach(), f"{k}_w": w.detach(), f"{k}_drgb": r.grad, f"{k}_dsigma": s.grad,
+                        f"{k}_loss": loss.detach()})
+        out.update({f"{tag}_rgb": rgb, f"{tag}_sigma": sigma, f"{tag}_z": z, f"{tag}_tgt": tgt})
+    # legacy free function (1e10 tail, colour only): src/utils/get_rays.py:198-236
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        out["legacy_c"] = legacy.volume_render(out["a_rgb"], out["a_sigma"], out["a_z"])
+    save("g6_composite.npz", **out)
+
+
+# ---------------------------------------------------------------- G7 analytic scene
+def g7():
+    """Ground-truth renders of the analytic torus+sphere field (the scene of
+    src/train_nerf.py:48-66 with an indexable focal), small enough to ship."""
+    H = W = 24
+    n = 32
+    views = []
+    for k in range(6):
+        ang = 2 * np.pi * k / 6
+        eye = torch.tensor([3.0 * np.cos(ang), 3.0 * np.sin(ang), 1.0], dtype=torch.float32)
+        # the reference's look-at camera faces away from its target (rays go along -forward),
+        # so aim it at the mirrored point to see the object
+        cam = Camera(eye=eye, target=2 * eye, focal=(30.0, 30.0), H=H, W=W, up=torch.tensor([0.0, 0.0, 1.0]))
+        ro, rd = cam.get_rays()
+        pts, z = Camera.sample_points_along_rays(ro, rd, 1.0, 5.0, n, perturb=False)
+        rgb, sigma = legacy.evaluate_fake_radiance_field_complex(pts)
+        img, _ = Camera.volume_render(rgb, sigma * 5.0, z)
+        views.append((cam.c2w, img))
+    save("g7_scene.npz", c2w=torch.stack([v[0] for v in views]), img=torch.stack([v[1] for v in views]),
+         cfg=np.array([H, W, 30.0, 1.0, 5.0, n]))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    o1 = g1()
+    o2 = g2(o1)
+    g3()
+    g4()
+    g5()
+    g6(o2)
+    g7()
