@@ -1,0 +1,149 @@
+/*
+ * nerf_hip.h -- C ABI of libnerf_hip.so: the NeRF render/train hot path as
+ * hand-written gfx950 (MI355X) HIP kernels.
+ *
+ * The reference (skowae/NeRF) is pure Python/PyTorch and has no FFI of its
+ * own; each entry point below names the reference function whose body it
+ * replaces (paths relative to the reference checkout).  Conventions:
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - all tensors are dense row-major float32 unless stated;
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library
+ *     never allocates and keeps no state between calls;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the
+ *     default stream) and the call returns without synchronising;
+ *   - the return value is 0 on success or a negative NERF_E* code, and
+ *     nerf_last_error() gives the thread-local message of the last failure.
+ * Thread safety: calls are re-entrant; they may come from any host thread
+ * (PyTorch runs backward on its own thread).
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_ABI_VERSION 1
+#define NERF_OK 0
+#define NERF_EINVAL (-22) /* bad argument (shape, null pointer, unsupported size) */
+#define NERF_ELAUNCH (-5) /* the HIP runtime rejected a launch                    */
+
+int nerf_abi_version(void);
+const char* nerf_last_error(void);
+
+/* ---------------------------------------------------------------- rays ---- */
+
+/* Camera.get_rays, src/Camera.py:49-72.  c2w: 12 floats, rows of the 3x4 pose.
+ * Pixel id p = row*W + col.  pix == NULL renders all H*W pixels in order (R must
+ * be H*W); otherwise pix holds R int32 pixel ids.  rays_o, rays_d: [R,3]. */
+int nerf_raygen(const float* c2w, float fx, float fy, float cx, float cy, int H, int W,
+                const int32_t* pix, int64_t R, float* rays_o, float* rays_d, void* stream);
+
+/* Camera.sample_points_along_rays, src/Camera.py:127-141.  z_lin: the N base
+ * depths (torch.linspace(near, far, N), computed by the caller so that the
+ * values are the reference's bit for bit).  u: [R,N] uniforms in [0,1) that the
+ * reference would draw with torch.rand_like, or NULL for perturb=False.
+ * Outputs z_vals [R,N] and pts [R,N,3] (either may be NULL). */
+int nerf_stratified_sample(const float* rays_o, const float* rays_d, const float* z_lin,
+                           const float* u, int64_t R, int N, float* z_vals, float* pts,
+                           void* stream);
+
+/* Fused form of the two calls above: rays are generated and sampled without a
+ * round trip through memory.  Any of rays_o/rays_d/z_vals/pts may be NULL. */
+int nerf_raygen_sample(const float* c2w, float fx, float fy, float cx, float cy, int H, int W,
+                       const int32_t* pix, int64_t R, const float* z_lin, const float* u, int N,
+                       float* rays_o, float* rays_d, float* z_vals, float* pts, void* stream);
+
+/* Hierarchical inverse-CDF sampling (NeRF 2020 section 5.2).  The reference has
+ * no such stage; the semantics are those of oracle/nerf_oracle.py:sample_pdf.
+ * z [R,Nc], weights [R,Nc], u [R,Nf] -> z_fine [R,Nf], idx int32 [R,Nf] (may be
+ * NULL), z_all [R,Nc+Nf] sorted, pts [R,Nc+Nf,3] (may be NULL).
+ * Limits: 3 <= Nc <= 256, 1 <= Nf, Nc+Nf <= 1024. */
+int nerf_pdf_sample(const float* rays_o, const float* rays_d, const float* z, const float* weights,
+                    const float* u, int64_t R, int Nc, int Nf, float* z_fine, int32_t* idx,
+                    float* z_all, float* pts, void* stream);
+
+/* Forward-facing NDC ray transform (NeRF 2020 appendix C); not in the reference,
+ * semantics of oracle/nerf_oracle.py:ndc_rays.  In/out [R,3]; in-place allowed. */
+int nerf_ndc_rays(const float* rays_o, const float* rays_d, int64_t R, int H, int W, float focal,
+                  float near_, float* out_o, float* out_d, void* stream);
+
+/* ------------------------------------------------------------ encoders ---- */
+
+/* PositionalEncoding.forward, src/utils/positional_encoding.py:21-36 with
+ * log-scale bands 2^k and include_input: x [P,D] -> out [P, D*(2L+1)]. */
+int nerf_encode_pe(const float* x, int64_t P, int D, int L, float* out, void* stream);
+
+/* HashGridEncoder.forward, src/utils/hash_grid_encoder.py:42-107.
+ * tables: host array of `levels` device pointers, level l holding
+ * sizes[l] rows of 2 floats; res, sizes: host int arrays.  out [P, 2*levels].
+ * idx_dump (may be NULL): int32 [levels,8,P] hashed row of every corner in the
+ * reference's order c000,c001,...,c111; w_dump (may be NULL): [levels,P,3]. */
+int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* tables, const int* res,
+                      const int* sizes, int levels, float* out, int32_t* idx_dump, float* w_dump,
+                      void* stream);
+
+/* Backward of the above w.r.t. the tables (the reference gets it from the
+ * dense nn.Embedding gradient).  d_out [P, 2*levels]; d_tables: host array of
+ * device pointers, ACCUMULATED into with float atomics (zero them first). */
+int nerf_hashgrid_bwd(const float* x, int64_t P, const float* d_out, const int* res,
+                      const int* sizes, int levels, float* const* d_tables, void* stream);
+
+/* ----------------------------------------------------------- composite ---- */
+
+/* Camera.volume_render, src/Camera.py:143-183.  rgb [R,N,3], sigma [R,N],
+ * z [R,N] -> out_rgb [R,3], weights [R,N]; depth [R] = sum w*z (may be NULL; the
+ * reference has no depth output).  2 <= N <= 1024 (for N = 1 the reference's
+ * tail-distance concat yields empty tensors; that case is rejected here). */
+int nerf_composite_fwd(const float* rgb, const float* sigma, const float* z, int64_t R, int N,
+                       int white_bkgd, float* out_rgb, float* weights, float* depth, void* stream);
+
+/* Backward of volume_render for a loss that reads out_rgb, weights and depth
+ * (the reference's NGP loss uses both outputs, src/train_nerf_ngp.py:221-222).
+ * d_out [R,3]; d_weights [R,N] and d_depth [R] may be NULL (zero).
+ * Outputs d_rgb [R,N,3], d_sigma [R,N]. */
+int nerf_composite_bwd(const float* rgb, const float* sigma, const float* z, const float* d_out,
+                       const float* d_weights, const float* d_depth, int64_t R, int N,
+                       int white_bkgd, float* d_rgb, float* d_sigma, void* stream);
+
+/* ---------------------------------------------------------- fused MLPs ---- */
+
+/* Vanilla 8x256 NeRF MLP: NeRF.forward (src/models/NeRF.py:67-109) and
+ * FastMLPNeRF.forward (src/models/FastMLPNeRF.py:47-70), which differ only in
+ * the column order of the layer-4 weight (skip_h_first = 0: [x_enc | h],
+ * 1: [h | x_enc]).
+ *
+ * Parameter block `params`: host array of 24 device pointers in the order
+ *   W0,b0, ... ,W7,b7, Wsigma,bsigma, Wfeat,bfeat, Wrgb0,brgb0, Wrgb2,brgb2
+ * with the nn.Linear shapes (out,in): (256,63) (256,256)x3 (256,319)
+ * (256,256)x3 (1,256) (256,256) (128,283) (3,128).
+ */
+#define NERF_VANILLA_NPARAM 24
+
+/* Floats of packed-weight scratch needed by the forward / backward kernels. */
+size_t nerf_mlp_vanilla_pack_floats(void);
+/* Re-order the weights into the per-lane MFMA operand layout. */
+int nerf_mlp_vanilla_pack(const float* const* params, int skip_h_first, float* packed,
+                          void* stream);
+/* Floats per point of the forward's activation workspace (kept for backward)
+ * and of the backward's own scratch (per-layer pre-activation gradients). */
+size_t nerf_mlp_vanilla_ws_floats_per_point(void);
+size_t nerf_mlp_vanilla_ws2_floats_per_point(void);
+/* x [P,3], dirs [P,3] -> rgb [P,3], sigma [P].  ws: workspace of
+ * ceil32(P)*ws_floats_per_point floats, or NULL for inference. */
+int nerf_mlp_vanilla_fwd(const float* x, const float* dirs, int64_t P, const float* packed,
+                         float* rgb, float* sigma, float* ws, void* stream);
+/* d_rgb [P,3], d_sigma [P] -> parameter gradients, ACCUMULATED into `grads`
+ * (host array of 24 device pointers, same order/shapes as params).
+ * ws is the forward's workspace; ws2: ceil32(P)*ws_floats_per_point floats. */
+int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, int64_t P, const float* packed,
+                         const float* rgb, const float* sigma, float* ws, float* ws2,
+                         int skip_h_first, float* const* grads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

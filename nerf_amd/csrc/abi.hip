@@ -1,0 +1,12 @@
+// Library-wide pieces of the C ABI: version and the thread-local error string.
+#include "common.h"
+
+namespace nerf {
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+}  // namespace nerf
+
+extern "C" int nerf_abi_version(void) { return NERF_ABI_VERSION; }
+extern "C" const char* nerf_last_error(void) { return nerf::err_buf(); }

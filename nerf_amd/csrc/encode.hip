@@ -1,0 +1,194 @@
+// Input encoders for gfx950: sin/cos positional encoding and the
+// multiresolution hash grid (forward gather + trilinear interpolation, backward
+// scatter with float atomics).  Compiled with -ffp-contract=off so the
+// interpolation rounds like the reference's separate PyTorch ops.
+#include "common.h"
+
+namespace nerf {
+
+// ------------------------------------------------------------------ PE ----
+// out[p][0:D] = x; out[p][D + 2*D*f + D*s + c] = (s ? cos : sin)(2^f * x[p][c])
+// (src/utils/positional_encoding.py:30-36).  One thread per output element so
+// that the [P, D(2L+1)] rows are written fully coalesced.
+__global__ void encode_pe_kernel(const float* __restrict__ x, int64_t P, int D, int L, float* __restrict__ out) {
+    const int width = D * (2 * L + 1);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P * width) return;
+    const int64_t p = t / width;
+    const int col = (int)(t - p * width);
+    if (col < D) {
+        out[t] = x[p * D + col];
+        return;
+    }
+    const int q = col - D;
+    const int f = q / (2 * D);
+    const int r = q - f * 2 * D;
+    const int s = r / D, c = r - s * D;
+    const float arg = ldexpf(x[p * D + c], f);  // 2^f * x, exact like the reference's fp32 product
+    out[t] = s ? cosf(arg) : sinf(arg);
+}
+
+// ----------------------------------------------------------- hash grid ----
+constexpr int HG_MAX_LEVELS = 32;
+
+struct HashLevels {
+    const float* table[HG_MAX_LEVELS];
+    int res[HG_MAX_LEVELS];
+    unsigned size[HG_MAX_LEVELS];
+};
+struct HashGradLevels {
+    float* table[HG_MAX_LEVELS];
+    int res[HG_MAX_LEVELS];
+    unsigned size[HG_MAX_LEVELS];
+};
+
+// Floor-modulo of a possibly negative cell coordinate (Python's % on int64,
+// src/utils/hash_grid_encoder.py:68-69).
+__device__ __forceinline__ unsigned wrap(long long v, int res) {
+    long long m = v % res;
+    if (m < 0) m += res;
+    return (unsigned)m;
+}
+
+// ((x*1 + y*2654435761 + z*805459861) & 0xFFFFFFFF) % size in the reference's
+// int64 arithmetic equals the 32-bit wrap-around sum (src/utils/hash_grid_encoder.py:39-40).
+__device__ __forceinline__ unsigned hash_row(unsigned cx, unsigned cy, unsigned cz, unsigned size) {
+    return (cx + cy * 2654435761u + cz * 805459861u) % size;
+}
+
+struct Cell {
+    unsigned lo[3], hi[3];
+    float w[3];
+};
+
+__device__ __forceinline__ Cell locate(const float* __restrict__ x, int64_t p, int res) {
+    Cell c;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float pos = x[p * 3 + k] * (float)res;   // :57
+        const float fl = floorf(pos);
+        const long long p0 = (long long)fl;           // :60
+        c.w[k] = pos - fl;                             // :64 (before wrapping)
+        c.lo[k] = wrap(p0, res);
+        c.hi[k] = wrap(p0 + 1, res);
+    }
+    return c;
+}
+
+// grid.y = level, one thread per point: a workgroup gathers from one table, so
+// the small tables stay in L2 and the large ones in the Infinity Cache.
+__global__ void hashgrid_fwd_kernel(const float* __restrict__ x, int64_t P, HashLevels lv, int levels,
+                                    float* __restrict__ out, int32_t* __restrict__ idx_dump,
+                                    float* __restrict__ w_dump) {
+    const int l = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const Cell c = locate(x, p, lv.res[l]);
+    const float2* __restrict__ tab = reinterpret_cast<const float2*>(lv.table[l]);
+    float2 f[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {  // 000,001,...,111 = (x,y,z) offsets
+        const unsigned row = hash_row((corner & 4) ? c.hi[0] : c.lo[0], (corner & 2) ? c.hi[1] : c.lo[1],
+                                      (corner & 1) ? c.hi[2] : c.lo[2], lv.size[l]);
+        f[corner] = tab[row];
+        if (idx_dump) idx_dump[((int64_t)l * 8 + corner) * P + p] = (int32_t)row;
+    }
+    if (w_dump) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w_dump[((int64_t)l * P + p) * 3 + k] = c.w[k];
+    }
+    const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
+    float r[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const float v000 = ch ? f[0].y : f[0].x, v001 = ch ? f[1].y : f[1].x, v010 = ch ? f[2].y : f[2].x,
+                    v011 = ch ? f[3].y : f[3].x, v100 = ch ? f[4].y : f[4].x, v101 = ch ? f[5].y : f[5].x,
+                    v110 = ch ? f[6].y : f[6].x, v111 = ch ? f[7].y : f[7].x;
+        const float x00 = v000 * (1.0f - wx) + v100 * wx;  // :95-98
+        const float x01 = v001 * (1.0f - wx) + v101 * wx;
+        const float x10 = v010 * (1.0f - wx) + v110 * wx;
+        const float x11 = v011 * (1.0f - wx) + v111 * wx;
+        const float y0 = x00 * (1.0f - wy) + x10 * wy;      // :100-101
+        const float y1 = x01 * (1.0f - wy) + x11 * wy;
+        r[ch] = y0 * (1.0f - wz) + y1 * wz;                 // :103
+    }
+    *reinterpret_cast<float2*>(out + p * (2 * levels) + 2 * l) = make_float2(r[0], r[1]);
+}
+
+// d table[row(corner)] += weight(corner) * d_out, weight = product of (w or 1-w).
+__global__ void hashgrid_bwd_kernel(const float* __restrict__ x, int64_t P, const float* __restrict__ d_out,
+                                    HashGradLevels lv, int levels) {
+    const int l = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const Cell c = locate(x, p, lv.res[l]);
+    const float2 g = *reinterpret_cast<const float2*>(d_out + p * (2 * levels) + 2 * l);
+    float* __restrict__ tab = lv.table[l];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const unsigned row = hash_row((corner & 4) ? c.hi[0] : c.lo[0], (corner & 2) ? c.hi[1] : c.lo[1],
+                                      (corner & 1) ? c.hi[2] : c.lo[2], lv.size[l]);
+        const float wgt = (((corner & 4) ? c.w[0] : 1.0f - c.w[0]) * ((corner & 2) ? c.w[1] : 1.0f - c.w[1])) *
+                          ((corner & 1) ? c.w[2] : 1.0f - c.w[2]);
+        atomicAdd(tab + 2 * (size_t)row + 0, wgt * g.x);
+        atomicAdd(tab + 2 * (size_t)row + 1, wgt * g.y);
+    }
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+extern "C" int nerf_encode_pe(const float* x, int64_t P, int D, int L, float* out, void* stream) {
+    if (P == 0) return NERF_OK;
+    NERF_REQUIRE(x && out, "nerf_encode_pe: null pointer");
+    NERF_REQUIRE(P >= 0 && D >= 1 && L >= 0 && L <= 32, "nerf_encode_pe: bad size P=%lld D=%d L=%d", (long long)P, D, L);
+    const int64_t n = P * D * (2 * L + 1);
+    hipLaunchKernelGGL(encode_pe_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, P, D, L,
+                       out);
+    return check_launch("nerf_encode_pe");
+}
+
+static int fill_levels(const int* res, const int* sizes, int levels, int* res_out, unsigned* size_out) {
+    for (int l = 0; l < levels; ++l) {
+        if (res[l] < 1 || sizes[l] < 1) return fail(NERF_EINVAL, "hashgrid: level %d has res=%d size=%d", l, res[l], sizes[l]);
+        res_out[l] = res[l];
+        size_out[l] = (unsigned)sizes[l];
+    }
+    return NERF_OK;
+}
+
+extern "C" int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* tables, const int* res,
+                                 const int* sizes, int levels, float* out, int32_t* idx_dump, float* w_dump,
+                                 void* stream) {
+    if (P == 0) return NERF_OK;
+    NERF_REQUIRE(x && tables && res && sizes && out, "nerf_hashgrid_fwd: null pointer");
+    NERF_REQUIRE(levels >= 1 && levels <= HG_MAX_LEVELS, "nerf_hashgrid_fwd: levels=%d outside [1,%d]", levels, HG_MAX_LEVELS);
+    NERF_REQUIRE(P >= 0, "nerf_hashgrid_fwd: P=%lld", (long long)P);
+    HashLevels lv;
+    if (int rc = fill_levels(res, sizes, levels, lv.res, lv.size)) return rc;
+    for (int l = 0; l < levels; ++l) {
+        NERF_REQUIRE(tables[l], "nerf_hashgrid_fwd: table %d is null", l);
+        lv.table[l] = tables[l];
+    }
+    hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3((unsigned)ceil_div(P, 256), levels), dim3(256), 0, (hipStream_t)stream, x,
+                       P, lv, levels, out, idx_dump, w_dump);
+    return check_launch("nerf_hashgrid_fwd");
+}
+
+extern "C" int nerf_hashgrid_bwd(const float* x, int64_t P, const float* d_out, const int* res, const int* sizes,
+                                 int levels, float* const* d_tables, void* stream) {
+    if (P == 0) return NERF_OK;
+    NERF_REQUIRE(x && d_out && res && sizes && d_tables, "nerf_hashgrid_bwd: null pointer");
+    NERF_REQUIRE(levels >= 1 && levels <= HG_MAX_LEVELS, "nerf_hashgrid_bwd: levels=%d outside [1,%d]", levels, HG_MAX_LEVELS);
+    NERF_REQUIRE(P >= 0, "nerf_hashgrid_bwd: P=%lld", (long long)P);
+    HashGradLevels lv;
+    if (int rc = fill_levels(res, sizes, levels, lv.res, lv.size)) return rc;
+    for (int l = 0; l < levels; ++l) {
+        NERF_REQUIRE(d_tables[l], "nerf_hashgrid_bwd: gradient table %d is null", l);
+        lv.table[l] = d_tables[l];
+    }
+    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)ceil_div(P, 256), levels), dim3(256), 0, (hipStream_t)stream, x,
+                       P, d_out, lv, levels);
+    return check_launch("nerf_hashgrid_bwd");
+}

@@ -1,0 +1,255 @@
+// Building blocks of the fused MLP kernels (gfx950, exact-f32 MFMA).
+//
+// Data layout idea.  v_mfma_f32_32x32x2_f32 computes D[32x32] += A[32x2] B[2x32]:
+//   A: lane l holds A[i = l&31][k = l>>5]      B: lane l holds B[k = l>>5][j = l&31]
+//   D: lane l, register r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+// A wavefront owns 32 points (the MFMA column j) and keeps a whole activation
+// vector per point in registers: tile t, register r of lane (p, h) is neuron
+// 32t + rowmap(r, h) of point p.  Register r of such a tile is then exactly the B
+// operand of one k-step of the next layer (its two k values are the rows held by
+// the two lane halves), so activations flow from one layer's accumulators into
+// the next layer's MFMAs without touching LDS.  The weights are re-ordered once
+// per step ("packed") so that the A operand of every MFMA is one coalesced
+// 256-byte read: pack[kt][r][lane][ot] = W[32*ot + (lane&31)][32*kt + rowmap(r, lane>>5)].
+#pragma once
+#include "common.h"
+
+namespace nerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ __forceinline__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// acc[ot] += W_tile(ot, kt) * in[kt] for all tiles.  wp: packed [KT][16][64][OT].
+template <int KT, int OT>
+__device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16 (&in)[KT], f32x16 (&acc)[OT],
+                                      int lane) {
+    static_assert(OT % 4 == 0, "OT must be a multiple of 4");
+    constexpr int V = OT / 4;
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane * V;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a[OT];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float4 t = w4[(size_t)((kt * 16 + r) * 64) * V + v];
+                a[4 * v + 0] = t.x;
+                a[4 * v + 1] = t.y;
+                a[4 * v + 2] = t.z;
+                a[4 * v + 3] = t.w;
+            }
+            const float b = in[kt][r];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ot], b, acc[ot], 0, 0, 0);
+        }
+    }
+}
+
+// acc tiles <- per-neuron vector v[32*t + rowmap(r,h)] (bias as the initial accumulator).
+template <int NT>
+__device__ __forceinline__ void fill_rows(f32x16 (&acc)[NT], const float* __restrict__ v, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = *reinterpret_cast<const float4*>(v + 32 * t + 8 * q + 4 * h);
+            acc[t][4 * q + 0] = b.x;
+            acc[t][4 * q + 1] = b.y;
+            acc[t][4 * q + 2] = b.z;
+            acc[t][4 * q + 3] = b.w;
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_tiles(f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[t][r] = fmaxf(a[t][r], 0.0f);
+}
+
+// Store the lane's part of a point's activation row: row -> this point's row
+// (row-major [P][width]); each (t,q) group is 4 consecutive neurons = one float4.
+template <int NT>
+__device__ __forceinline__ void store_row(float* __restrict__ row, const f32x16 (&a)[NT], int h, bool valid) {
+    if (!valid) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(row + 32 * t + 8 * q + 4 * h) =
+                make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
+}
+
+// One bit per neuron: 1 where the (post-ReLU) activation is > 0.  Word t>>1, bit (t&1)*16 + r.
+template <int NT>
+__device__ __forceinline__ uint4 relu_bits(const f32x16 (&a)[NT]) {
+    static_assert(NT <= 8, "at most 8 tiles fit 128 bits");
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[t >> 1] |= min(__float_as_uint(a[t][r]), 1u) << ((t & 1) * 16 + r);
+    return make_uint4(m[0], m[1], m[2], m[3]);
+}
+
+// a[t][r] = bit ? a[t][r] : 0
+template <int NT>
+__device__ __forceinline__ void apply_bits(f32x16 (&a)[NT], uint4 bits) {
+    const unsigned m[4] = {bits.x, bits.y, bits.z, bits.w};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int keep = ((int)(m[t >> 1] << (31 - ((t & 1) * 16 + r)))) >> 31;  // 0 or -1
+            a[t][r] = __uint_as_float(__float_as_uint(a[t][r]) & (unsigned)keep);
+        }
+}
+
+// Element e of the positional encoding of a 3-vector with L frequency bands:
+// [x, sin(2^0 x), cos(2^0 x), ...] (src/utils/positional_encoding.py:30-36); 0 beyond the end.
+__device__ __forceinline__ float pe_element(float x0, float x1, float x2, int e, int L) {
+    if (e >= 3 * (2 * L + 1)) return 0.0f;
+    int c, f = 0, s = -1;
+    if (e < 3) {
+        c = e;
+    } else {
+        const int q = e - 3;
+        f = q / 6;
+        const int rr = q - 6 * f;
+        s = rr >= 3;
+        c = rr - 3 * s;
+    }
+    const float xc = c == 0 ? x0 : (c == 1 ? x1 : x2);
+    if (s < 0) return xc;
+    const float arg = ldexpf(xc, f);
+    return s ? cosf(arg) : sinf(arg);
+}
+
+// Encoded tile(s) in the register layout: tile t, register r = element 32t + rowmap(r,h).
+template <int NT>
+__device__ __forceinline__ void pe_tiles(f32x16 (&out)[NT], float x0, float x1, float x2, int L, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[t][r] = pe_element(x0, x1, x2, 32 * t + rowmap(r, 0) + 4 * h, L);
+}
+
+__device__ __forceinline__ float softplus_f(float x) {  // F.softplus, beta 1, threshold 20
+    return x > 20.0f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Sum over neurons of a[t][r] * v[32t + rowmap(r,h)], reduced across the two lane halves.
+template <int NT>
+__device__ __forceinline__ float dot_rows(const f32x16 (&a)[NT], const float* __restrict__ v, int h) {
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4*>(v + 32 * t + 8 * q + 4 * h);
+            s = fmaf(a[t][4 * q + 0], w.x, s);
+            s = fmaf(a[t][4 * q + 1], w.y, s);
+            s = fmaf(a[t][4 * q + 2], w.z, s);
+            s = fmaf(a[t][4 * q + 3], w.w, s);
+        }
+    return s + __shfl_xor(s, 32, 64);
+}
+
+// ---------------------------------------------------------------------------
+// Weight packing jobs (run once per optimiser step).
+// ---------------------------------------------------------------------------
+struct PackJob {
+    const float* src;  // nn.Linear weight [N][ld] (row = output neuron)
+    int dst;           // float offset in the packed buffer
+    int ld, N;         // source leading dimension and row count
+    int mode;          // 0: forward pack, 1: backward (transposed) pack, 2: plain copy of `count` floats
+    int KT, OT;        // tiles of the contraction / output dimension of the packed operand
+    int seg_eff[2], seg_len[2], seg_src[2];  // forward: effective input k in [eff, eff+len) reads column src + (k-eff)
+    int col_begin, col_count;                 // backward: output m < col_count reads column col_begin + m
+    int count;                                // copy mode
+};
+constexpr int MAX_PACK_JOBS = 40;
+struct PackJobs {
+    PackJob job[MAX_PACK_JOBS];
+    int n;
+};
+
+int launch_pack(const PackJobs& jobs, float* packed, hipStream_t stream);
+
+// ---------------------------------------------------------------------------
+// Weight-gradient work list: dW[n][col_off + k] += sum_p dY[p][n] * X[p][k].
+// ---------------------------------------------------------------------------
+struct WgradPart {
+    const float* dY;   // [P32][ldY], columns n_off .. n_off + N
+    const float* X;    // [P32][ldX], columns 0 .. 32*KT
+    float* dW;         // nn.Linear gradient [N][ldW]
+    float* dbias;      // [N] or null
+    int ldY, ldX, ldW;
+    int col_off;       // first gradient column written
+    int k_valid;       // columns >= k_valid are padding and are not written
+    int shape;         // index into the (NTW, KT) instantiation list
+    int slabs;         // point slabs this part is split into
+    int first_block;   // prefix sum of slabs
+};
+constexpr int MAX_WGRAD_PARTS = 24;
+struct WgradParts {
+    WgradPart part[MAX_WGRAD_PARTS];
+    int n;
+    int total_blocks;
+    long long P32;
+};
+
+// Gradients of heads with at most 4 outputs (sigma, rgb): dW[c][k] += sum_p dY[p][c0+c] X[p][k].
+struct SkinnyPart {
+    const float* dY;  // [P32][ldY]
+    const float* X;   // [P32][ldX]
+    float* dW;        // [C][K]
+    float* dbias;     // [C]
+    int ldY, ldX, c0, C, K;
+};
+
+// Fills slabs/first_block/total_blocks and launches one workgroup per slab.
+int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream);
+int launch_skinny(const SkinnyPart& part, long long P32, hipStream_t stream);
+
+inline PackJob pack_fwd_job(const float* src, int ld, int N, int dst, int KT, int OT, int eff0, int len0, int src0,
+                            int eff1 = 0, int len1 = 0, int src1 = 0) {
+    PackJob j{};
+    j.src = src; j.dst = dst; j.ld = ld; j.N = N; j.mode = 0; j.KT = KT; j.OT = OT;
+    j.seg_eff[0] = eff0; j.seg_len[0] = len0; j.seg_src[0] = src0;
+    j.seg_eff[1] = eff1; j.seg_len[1] = len1; j.seg_src[1] = src1;
+    return j;
+}
+inline PackJob pack_bwd_job(const float* src, int ld, int N, int dst, int KT, int OT, int col_begin, int col_count) {
+    PackJob j{};
+    j.src = src; j.dst = dst; j.ld = ld; j.N = N; j.mode = 1; j.KT = KT; j.OT = OT;
+    j.col_begin = col_begin; j.col_count = col_count;
+    return j;
+}
+inline PackJob pack_copy_job(const float* src, int dst, int count) {
+    PackJob j{};
+    j.src = src; j.dst = dst; j.mode = 2; j.count = count;
+    return j;
+}
+inline WgradPart wgrad_part_desc(const float* dY, int ldY, const float* X, int ldX, float* dW, int ldW, int col_off,
+                                 int k_valid, float* dbias, int shape) {
+    WgradPart p{};
+    p.dY = dY; p.ldY = ldY; p.X = X; p.ldX = ldX; p.dW = dW; p.ldW = ldW; p.col_off = col_off; p.k_valid = k_valid;
+    p.dbias = dbias; p.shape = shape;
+    return p;
+}
+
+}  // namespace nerf

@@ -1,0 +1,323 @@
+// Fused 8x256 NeRF MLP for gfx950 (NeRF.forward, src/models/NeRF.py:67-109;
+// FastMLPNeRF.forward, src/models/FastMLPNeRF.py:47-70).
+//
+// Forward: one wavefront per 32 points; positional encodings are computed in
+// registers, every layer is a chain of exact-f32 MFMAs whose accumulators become
+// the next layer's B operands (see mlp_common.h), weights stream from the
+// packed buffer (L2-resident, 2.4 MB).  For training the activations are written
+// row-major for the weight-gradient GEMMs plus one ReLU bit per neuron for the
+// backward-data kernel.
+// Backward: (1) a fused backward-data chain in the same register layout that
+// emits d(pre-activation) of every layer, (2) one work-list launch of
+// weight-gradient GEMMs contracting over points, (3) two small-head reductions.
+#include "mlp_common.h"
+
+namespace nerf {
+namespace vp {  // float offsets into the packed buffer
+constexpr int T88 = 8 * 16 * 64 * 8;
+constexpr int F_L0 = 0;                     // 63(64) -> 256
+constexpr int F_L1 = F_L0 + 2 * 16 * 64 * 8;  // layers 1,2,3
+constexpr int F_L4X = F_L1 + 3 * T88;       // layer 4, x_enc columns
+constexpr int F_L4H = F_L4X + 2 * 16 * 64 * 8;
+constexpr int F_L5 = F_L4H + T88;           // layers 5,6,7
+constexpr int F_FEAT = F_L5 + 3 * T88;
+constexpr int F_RGB0F = F_FEAT + T88;       // rgb hidden layer, feature columns (256 -> 128)
+constexpr int F_RGB0D = F_RGB0F + 8 * 16 * 64 * 4;  // view-direction columns (27(32) -> 128)
+constexpr int B_RGB0 = F_RGB0D + 1 * 16 * 64 * 4;   // transposed: 128 -> 256 (feature columns only)
+constexpr int B_FEAT = B_RGB0 + 4 * 16 * 64 * 8;
+constexpr int B_L7 = B_FEAT + T88;          // layers 7,6,5,4(h columns),3,2,1
+constexpr int S_BIAS = B_L7 + 7 * T88;      // b0..b7
+constexpr int S_BF = S_BIAS + 8 * 256;
+constexpr int S_B1 = S_BF + 256;
+constexpr int S_WS = S_B1 + 128;
+constexpr int S_BS = S_WS + 256;
+constexpr int S_W2 = S_BS + 4;
+constexpr int S_B2 = S_W2 + 3 * 128;
+constexpr int TOTAL = S_B2 + 4;
+}  // namespace vp
+
+namespace vw {  // workspace layout, floats per point (multiply by P32 for the section offset)
+constexpr int XE = 0;        // [P32][64]
+constexpr int DE = 64;       // [P32][32]
+constexpr int H = 96;        // 8 x [P32][256]
+constexpr int FEAT = H + 8 * 256;
+constexpr int HR = FEAT + 256;  // [P32][128]
+constexpr int MASK = HR + 128;  // [P32/32][9][64][4] u32
+constexpr int PER_POINT = MASK + 72;
+// backward workspace
+constexpr int DY = 0;           // 8 x [P32][256]
+constexpr int DFEAT = 8 * 256;
+constexpr int DYR = DFEAT + 256;   // [P32][128]
+constexpr int DOUT4 = DYR + 128;   // [P32][4] = (d sigma_pre, d rgb_pre[3])
+constexpr int PER_POINT2 = DOUT4 + 4;
+}  // namespace vw
+
+struct TileIdx {
+    long long tile, gp, lp, P32;
+    int lane, p, h;
+    bool valid;
+};
+
+__device__ __forceinline__ bool tile_index(long long P, TileIdx& ix) {
+    ix.lane = threadIdx.x & 63;
+    ix.tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    ix.p = ix.lane & 31;
+    ix.h = ix.lane >> 5;
+    ix.gp = ix.tile * 32 + ix.p;
+    ix.valid = ix.gp < P;
+    ix.lp = ix.valid ? ix.gp : P - 1;
+    ix.P32 = (P + 31) / 32 * 32;
+    return ix.tile * 32 < P;
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dirs,
+                                                          long long P, const float* __restrict__ pk,
+                                                          float* __restrict__ rgb, float* __restrict__ sigma,
+                                                          float* __restrict__ ws) {
+    TileIdx ix;
+    if (!tile_index(P, ix)) return;
+    const int lane = ix.lane, h = ix.h;
+    const float x0 = x[3 * ix.lp], x1 = x[3 * ix.lp + 1], x2 = x[3 * ix.lp + 2];
+    uint4* mask_out = SAVE ? reinterpret_cast<uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane : nullptr;
+
+    f32x16 xe[2];
+    pe_tiles<2>(xe, x0, x1, x2, 10, h);
+    if (SAVE) store_row<2>(ws + ix.P32 * vw::XE + ix.gp * 64, xe, h, true);
+
+    f32x16 hc[8], acc[8];
+    // layer 0
+    fill_rows<8>(acc, pk + vp::S_BIAS, h);
+    dense<2, 8>(pk + vp::F_L0, xe, acc, lane);
+    relu_tiles<8>(acc);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) hc[t] = acc[t];
+    if (SAVE) {
+        store_row<8>(ws + ix.P32 * vw::H + ix.gp * 256, hc, h, true);
+        mask_out[0] = relu_bits<8>(hc);
+    }
+    auto finish_layer = [&](int l) {
+        relu_tiles<8>(acc);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) hc[t] = acc[t];
+        if (SAVE) {
+            store_row<8>(ws + ix.P32 * (vw::H + 256 * l) + ix.gp * 256, hc, h, true);
+            mask_out[l * 64] = relu_bits<8>(hc);
+        }
+    };
+#pragma unroll 1
+    for (int l = 1; l < 4; ++l) {
+        fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
+        dense<8, 8>(pk + vp::F_L1 + (l - 1) * vp::T88, hc, acc, lane);
+        finish_layer(l);
+    }
+    // skip connection: the layer-4 input is [x_enc | h] (either column order, see the packing)
+    fill_rows<8>(acc, pk + vp::S_BIAS + 256 * 4, h);
+    dense<2, 8>(pk + vp::F_L4X, xe, acc, lane);
+    dense<8, 8>(pk + vp::F_L4H, hc, acc, lane);
+    finish_layer(4);
+#pragma unroll 1
+    for (int l = 5; l < 8; ++l) {
+        fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
+        dense<8, 8>(pk + vp::F_L5 + (l - 5) * vp::T88, hc, acc, lane);
+        finish_layer(l);
+    }
+    // density head: softplus(w.h + b)   (NeRF.py:90)
+    const float sp = dot_rows<8>(hc, pk + vp::S_WS, h) + pk[vp::S_BS];
+    if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(sp);
+    // feature layer (no activation)      (NeRF.py:95)
+    fill_rows<8>(acc, pk + vp::S_BF, h);
+    dense<8, 8>(pk + vp::F_FEAT, hc, acc, lane);
+    if (SAVE) store_row<8>(ws + ix.P32 * vw::FEAT + ix.gp * 256, acc, h, true);
+    // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
+    f32x16 de[1];
+    pe_tiles<1>(de, dirs[3 * ix.lp], dirs[3 * ix.lp + 1], dirs[3 * ix.lp + 2], 4, h);
+    if (SAVE) store_row<1>(ws + ix.P32 * vw::DE + ix.gp * 32, de, h, true);
+    f32x16 hr[4];
+    fill_rows<4>(hr, pk + vp::S_B1, h);
+    dense<8, 4>(pk + vp::F_RGB0F, acc, hr, lane);
+    dense<1, 4>(pk + vp::F_RGB0D, de, hr, lane);
+    relu_tiles<4>(hr);
+    if (SAVE) {
+        store_row<4>(ws + ix.P32 * vw::HR + ix.gp * 128, hr, h, true);
+        mask_out[8 * 64] = relu_bits<4>(hr);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = dot_rows<4>(hr, pk + vp::S_W2 + 128 * c, h) + pk[vp::S_B2 + c];
+        if (ix.valid && h == 0) rgb[3 * ix.gp + c] = sigmoid_f(v);
+    }
+}
+
+// Backward-data chain.  Emits d(pre-activation) of every layer row-major into ws2.
+__global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __restrict__ d_rgb,
+                                                               const float* __restrict__ d_sigma, long long P,
+                                                               const float* __restrict__ pk,
+                                                               const float* __restrict__ rgb,
+                                                               const float* __restrict__ sigma,
+                                                               const float* __restrict__ ws, float* __restrict__ ws2) {
+    TileIdx ix;
+    if (!tile_index(P, ix)) return;
+    const int lane = ix.lane, h = ix.h;
+    const uint4* mask_in = reinterpret_cast<const uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane;
+    float dpre[3], dps = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float o = rgb[3 * ix.lp + c];
+        dpre[c] = ix.valid ? d_rgb[3 * ix.lp + c] * o * (1.0f - o) : 0.0f;   // sigmoid'
+    }
+    if (ix.valid) dps = d_sigma[ix.lp] * (1.0f - expf(-sigma[ix.lp]));          // softplus' = 1 - exp(-softplus)
+    if (h == 0) *reinterpret_cast<float4*>(ws2 + ix.P32 * vw::DOUT4 + ix.gp * 4) = make_float4(dps, dpre[0], dpre[1], dpre[2]);
+
+    // d hr = W2^T d rgb_pre, masked by the ReLU of the colour hidden layer
+    f32x16 dyr[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float4 w = *reinterpret_cast<const float4*>(pk + vp::S_W2 + 128 * c + 32 * t + 8 * q + 4 * h);
+                s.x = fmaf(w.x, dpre[c], s.x);
+                s.y = fmaf(w.y, dpre[c], s.y);
+                s.z = fmaf(w.z, dpre[c], s.z);
+                s.w = fmaf(w.w, dpre[c], s.w);
+            }
+            dyr[t][4 * q + 0] = s.x;
+            dyr[t][4 * q + 1] = s.y;
+            dyr[t][4 * q + 2] = s.z;
+            dyr[t][4 * q + 3] = s.w;
+        }
+    apply_bits<4>(dyr, mask_in[8 * 64]);
+    store_row<4>(ws2 + ix.P32 * vw::DYR + ix.gp * 128, dyr, h, true);
+
+    f32x16 a[8], b[8];
+    zero_tiles<8>(a);
+    dense<4, 8>(pk + vp::B_RGB0, dyr, a, lane);   // d feat
+    store_row<8>(ws2 + ix.P32 * vw::DFEAT + ix.gp * 256, a, h, true);
+    zero_tiles<8>(b);
+    dense<8, 8>(pk + vp::B_FEAT, a, b, lane);     // d h7 through the feature layer ...
+#pragma unroll
+    for (int t = 0; t < 8; ++t)                    // ... plus the density head
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4*>(pk + vp::S_WS + 32 * t + 8 * q + 4 * h);
+            b[t][4 * q + 0] = fmaf(w.x, dps, b[t][4 * q + 0]);
+            b[t][4 * q + 1] = fmaf(w.y, dps, b[t][4 * q + 1]);
+            b[t][4 * q + 2] = fmaf(w.z, dps, b[t][4 * q + 2]);
+            b[t][4 * q + 3] = fmaf(w.w, dps, b[t][4 * q + 3]);
+        }
+    apply_bits<8>(b, mask_in[7 * 64]);
+    store_row<8>(ws2 + ix.P32 * (vw::DY + 7 * 256) + ix.gp * 256, b, h, true);
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {                 // d h_{l-1} = W_l^T d y_l (h columns only at l = 4)
+        zero_tiles<8>(a);
+        dense<8, 8>(pk + vp::B_L7 + (7 - l) * vp::T88, b, a, lane);
+        apply_bits<8>(a, mask_in[(l - 1) * 64]);
+        store_row<8>(ws2 + ix.P32 * (vw::DY + (l - 1) * 256) + ix.gp * 256, a, h, true);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b[t] = a[t];
+    }
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+extern "C" size_t nerf_mlp_vanilla_pack_floats(void) { return vp::TOTAL; }
+extern "C" size_t nerf_mlp_vanilla_ws_floats_per_point(void) { return vw::PER_POINT; }
+extern "C" size_t nerf_mlp_vanilla_ws2_floats_per_point(void) { return vw::PER_POINT2; }
+
+extern "C" int nerf_mlp_vanilla_pack(const float* const* params, int skip_h_first, float* packed, void* stream) {
+    NERF_REQUIRE(params && packed, "nerf_mlp_vanilla_pack: null pointer");
+    for (int i = 0; i < NERF_VANILLA_NPARAM; ++i) NERF_REQUIRE(params[i], "nerf_mlp_vanilla_pack: parameter %d is null", i);
+    const float* const* W = params;
+    auto Wl = [&](int l) { return W[2 * l]; };
+    auto bl = [&](int l) { return W[2 * l + 1]; };
+    const float *Ws = W[16], *bs = W[17], *Wf = W[18], *bf = W[19], *W1 = W[20], *b1 = W[21], *W2 = W[22], *b2 = W[23];
+    // layer-4 column ranges: NeRF has [x_enc(63) | h(256)], FastMLPNeRF has [h(256) | x_enc(63)]
+    const int xe_col = skip_h_first ? 256 : 0, h_col = skip_h_first ? 0 : 63;
+    PackJobs J{};
+    int n = 0;
+    J.job[n++] = pack_fwd_job(Wl(0), 63, 256, vp::F_L0, 2, 8, 0, 63, 0);
+    for (int l = 1; l <= 3; ++l) J.job[n++] = pack_fwd_job(Wl(l), 256, 256, vp::F_L1 + (l - 1) * vp::T88, 8, 8, 0, 256, 0);
+    J.job[n++] = pack_fwd_job(Wl(4), 319, 256, vp::F_L4X, 2, 8, 0, 63, xe_col);
+    J.job[n++] = pack_fwd_job(Wl(4), 319, 256, vp::F_L4H, 8, 8, 0, 256, h_col);
+    for (int l = 5; l <= 7; ++l) J.job[n++] = pack_fwd_job(Wl(l), 256, 256, vp::F_L5 + (l - 5) * vp::T88, 8, 8, 0, 256, 0);
+    J.job[n++] = pack_fwd_job(Wf, 256, 256, vp::F_FEAT, 8, 8, 0, 256, 0);
+    J.job[n++] = pack_fwd_job(W1, 283, 128, vp::F_RGB0F, 8, 4, 0, 256, 0);
+    J.job[n++] = pack_fwd_job(W1, 283, 128, vp::F_RGB0D, 1, 4, 0, 27, 256);
+    J.job[n++] = pack_bwd_job(W1, 283, 128, vp::B_RGB0, 4, 8, 0, 256);
+    J.job[n++] = pack_bwd_job(Wf, 256, 256, vp::B_FEAT, 8, 8, 0, 256);
+    for (int l = 7; l >= 1; --l)
+        J.job[n++] = pack_bwd_job(Wl(l), l == 4 ? 319 : 256, 256, vp::B_L7 + (7 - l) * vp::T88, 8, 8, l == 4 ? h_col : 0, 256);
+    for (int l = 0; l < 8; ++l) J.job[n++] = pack_copy_job(bl(l), vp::S_BIAS + 256 * l, 256);
+    J.job[n++] = pack_copy_job(bf, vp::S_BF, 256);
+    J.job[n++] = pack_copy_job(b1, vp::S_B1, 128);
+    J.job[n++] = pack_copy_job(Ws, vp::S_WS, 256);
+    J.job[n++] = pack_copy_job(bs, vp::S_BS, 1);
+    J.job[n++] = pack_copy_job(W2, vp::S_W2, 384);
+    J.job[n++] = pack_copy_job(b2, vp::S_B2, 3);
+    J.n = n;
+    static_assert(MAX_PACK_JOBS >= 36, "pack job table too small");
+    return launch_pack(J, packed, (hipStream_t)stream);
+}
+
+extern "C" int nerf_mlp_vanilla_fwd(const float* x, const float* dirs, int64_t P, const float* packed, float* rgb,
+                                    float* sigma, float* ws, void* stream) {
+    if (P == 0) return NERF_OK;
+    NERF_REQUIRE(x && dirs && packed && rgb && sigma, "nerf_mlp_vanilla_fwd: null pointer");
+    NERF_REQUIRE(P >= 0, "nerf_mlp_vanilla_fwd: P=%lld", (long long)P);
+    const dim3 grid((unsigned)ceil_div(P, 128)), block(256);
+    if (ws)
+        hipLaunchKernelGGL(vanilla_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, dirs, (long long)P, packed, rgb,
+                           sigma, ws);
+    else
+        hipLaunchKernelGGL(vanilla_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, dirs, (long long)P, packed,
+                           rgb, sigma, ws);
+    return check_launch("nerf_mlp_vanilla_fwd");
+}
+
+extern "C" int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, int64_t P, const float* packed,
+                                    const float* rgb, const float* sigma, float* ws, float* ws2, int skip_h_first,
+                                    float* const* grads, void* stream) {
+    if (P == 0) return NERF_OK;
+    NERF_REQUIRE(d_rgb && d_sigma && packed && rgb && sigma && ws && ws2 && grads, "nerf_mlp_vanilla_bwd: null pointer");
+    for (int i = 0; i < NERF_VANILLA_NPARAM; ++i) NERF_REQUIRE(grads[i], "nerf_mlp_vanilla_bwd: gradient %d is null", i);
+    NERF_REQUIRE(P >= 0, "nerf_mlp_vanilla_bwd: P=%lld", (long long)P);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(vanilla_bwd_data_kernel, dim3((unsigned)ceil_div(P, 128)), dim3(256), 0, st, d_rgb, d_sigma,
+                       (long long)P, packed, rgb, sigma, ws, ws2);
+    if (int rc = check_launch("nerf_mlp_vanilla_bwd(data)")) return rc;
+
+    const long long P32 = (P + 31) / 32 * 32;
+    auto H = [&](int l) { return ws + P32 * (vw::H + 256 * l); };
+    auto DY = [&](int l) { return ws2 + P32 * (vw::DY + 256 * l); };
+    const float* XE = ws + P32 * vw::XE;
+    const float* DE = ws + P32 * vw::DE;
+    const float* FEAT = ws + P32 * vw::FEAT;
+    const float* HR = ws + P32 * vw::HR;
+    const float* DFEAT = ws2 + P32 * vw::DFEAT;
+    const float* DYR = ws2 + P32 * vw::DYR;
+    const float* DOUT4 = ws2 + P32 * vw::DOUT4;
+    const int xe_col = skip_h_first ? 256 : 0, h_col = skip_h_first ? 0 : 63;
+    WgradParts parts{};
+    int n = 0;
+    // ordered by decreasing cost so that the heavy slabs are dispatched first
+    for (int l = 1; l < 8; ++l)
+        parts.part[n++] = wgrad_part_desc(DY(l), 256, H(l - 1), 256, grads[2 * l], l == 4 ? 319 : 256, l == 4 ? h_col : 0, 256,
+                                          l == 4 ? nullptr : grads[2 * l + 1], 0);
+    parts.part[n++] = wgrad_part_desc(DFEAT, 256, H(7), 256, grads[18], 256, 0, 256, grads[19], 0);
+    parts.part[n++] = wgrad_part_desc(DYR, 128, FEAT, 256, grads[20], 283, 0, 256, grads[21], 2);
+    parts.part[n++] = wgrad_part_desc(DY(0), 256, XE, 64, grads[0], 63, 0, 63, grads[1], 1);
+    parts.part[n++] = wgrad_part_desc(DY(4), 256, XE, 64, grads[8], 319, xe_col, 63, grads[9], 1);
+    parts.part[n++] = wgrad_part_desc(DYR, 128, DE, 32, grads[20], 283, 256, 27, nullptr, 3);
+    parts.n = n;
+    if (int rc = launch_wgrad(parts, P32, st)) return rc;
+
+    SkinnyPart sg{DOUT4, H(7), grads[16], grads[17], 4, 256, 0, 1, 256};
+    if (int rc = launch_skinny(sg, P32, st)) return rc;
+    SkinnyPart rg{DOUT4, HR, grads[22], grads[23], 4, 128, 1, 3, 128};
+    return launch_skinny(rg, P32, st);
+}

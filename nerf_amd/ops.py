@@ -1,0 +1,254 @@
+"""Tensor-level wrappers and autograd Functions over the C ABI (libnerf_hip.so).
+
+PyTorch is used here for device memory, streams and the autograd graph only;
+all arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+# ---------------------------------------------------------------- rays ----
+def raygen(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int, W: int,
+           pix: Optional[torch.Tensor] = None):
+    """Rays of an H x W pinhole camera (all pixels, or the int32 pixel ids in ``pix``)."""
+    L.need_gpu(c2w, pix)
+    pose = L.f32c(c2w[:3, :4])
+    R = H * W if pix is None else pix.numel()
+    if pix is not None:
+        pix = pix.to(torch.int32).contiguous()
+    o = torch.empty(R, 3, device=pose.device, dtype=torch.float32)
+    d = torch.empty_like(o)
+    L.check(L.lib().nerf_raygen(L.ptr(pose), fx, fy, cx, cy, H, W, L.ptr(pix), R, L.ptr(o), L.ptr(d),
+                                L.stream_of(pose)), "nerf_raygen")
+    return o, d
+
+
+def stratified_sample(rays_o: torch.Tensor, rays_d: torch.Tensor, z_lin: torch.Tensor,
+                      u: Optional[torch.Tensor], want_pts: bool = True):
+    """rays [R,3], base depths z_lin [N], uniforms u [R,N] or None -> z [R,N], pts [R,N,3]."""
+    L.need_gpu(rays_o, rays_d, z_lin, u)
+    o, d, zl = L.f32c(rays_o), L.f32c(rays_d), L.f32c(z_lin)
+    R, N = o.shape[0], zl.numel()
+    if u is not None:
+        u = L.f32c(u)
+        assert u.shape == (R, N), f"u must be [{R},{N}], got {tuple(u.shape)}"
+    z = torch.empty(R, N, device=o.device, dtype=torch.float32)
+    pts = torch.empty(R, N, 3, device=o.device, dtype=torch.float32) if want_pts else None
+    L.check(L.lib().nerf_stratified_sample(L.ptr(o), L.ptr(d), L.ptr(zl), L.ptr(u), R, N, L.ptr(z), L.ptr(pts),
+                                           L.stream_of(o)), "nerf_stratified_sample")
+    return z, pts
+
+
+def raygen_sample(c2w, fx, fy, cx, cy, H, W, pix, z_lin, u):
+    """Fused ray generation + stratified sampling -> rays_o, rays_d [R,3], z [R,N], pts [R,N,3]."""
+    L.need_gpu(c2w, pix, z_lin, u)
+    pose = L.f32c(c2w[:3, :4])
+    zl = L.f32c(z_lin)
+    N = zl.numel()
+    R = H * W if pix is None else pix.numel()
+    if pix is not None:
+        pix = pix.to(torch.int32).contiguous()
+    if u is not None:
+        u = L.f32c(u)
+        assert u.shape == (R, N)
+    dev = pose.device
+    o = torch.empty(R, 3, device=dev)
+    d = torch.empty(R, 3, device=dev)
+    z = torch.empty(R, N, device=dev)
+    pts = torch.empty(R, N, 3, device=dev)
+    L.check(L.lib().nerf_raygen_sample(L.ptr(pose), fx, fy, cx, cy, H, W, L.ptr(pix), R, L.ptr(zl), L.ptr(u), N,
+                                       L.ptr(o), L.ptr(d), L.ptr(z), L.ptr(pts), L.stream_of(pose)),
+            "nerf_raygen_sample")
+    return o, d, z, pts
+
+
+def pdf_sample(rays_o, rays_d, z, weights, u, want_idx: bool = False):
+    """Inverse-CDF fine sampling -> z_fine [R,Nf], idx int32 [R,Nf] | None, z_all [R,Nc+Nf], pts [R,Nc+Nf,3]."""
+    L.need_gpu(rays_o, rays_d, z, weights, u)
+    o, d, z, w, u = (L.f32c(t) for t in (rays_o, rays_d, z, weights.detach(), u))
+    R, Nc = z.shape
+    Nf = u.shape[1]
+    dev = z.device
+    zf = torch.empty(R, Nf, device=dev)
+    idx = torch.empty(R, Nf, device=dev, dtype=torch.int32) if want_idx else None
+    z_all = torch.empty(R, Nc + Nf, device=dev)
+    pts = torch.empty(R, Nc + Nf, 3, device=dev)
+    L.check(L.lib().nerf_pdf_sample(L.ptr(o), L.ptr(d), L.ptr(z), L.ptr(w), L.ptr(u), R, Nc, Nf, L.ptr(zf), L.ptr(idx),
+                                    L.ptr(z_all), L.ptr(pts), L.stream_of(z)), "nerf_pdf_sample")
+    return zf, idx, z_all, pts
+
+
+def ndc_rays(H: int, W: int, focal: float, near: float, rays_o, rays_d):
+    L.need_gpu(rays_o, rays_d)
+    o, d = L.f32c(rays_o).reshape(-1, 3), L.f32c(rays_d).reshape(-1, 3)
+    oo, dd = torch.empty_like(o), torch.empty_like(d)
+    L.check(L.lib().nerf_ndc_rays(L.ptr(o), L.ptr(d), o.shape[0], H, W, focal, near, L.ptr(oo), L.ptr(dd),
+                                  L.stream_of(o)), "nerf_ndc_rays")
+    return oo.view(rays_o.shape), dd.view(rays_d.shape)
+
+
+# ------------------------------------------------------------ encoders ----
+def encode_pe(x: torch.Tensor, num_freqs: int) -> torch.Tensor:
+    """[..., D] -> [..., D*(2L+1)].  The encoder input carries no gradient in the
+    reference's pipelines (sample points are constants), so none is produced."""
+    L.need_gpu(x)
+    xc = L.f32c(x.detach())
+    D = xc.shape[-1]
+    P = xc.numel() // D
+    out = torch.empty(*xc.shape[:-1], D * (2 * num_freqs + 1), device=xc.device)
+    L.check(L.lib().nerf_encode_pe(L.ptr(xc), P, D, num_freqs, L.ptr(out), L.stream_of(xc)), "nerf_encode_pe")
+    return out
+
+
+class _HashGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, sizes, *tables):
+        L.need_gpu(x, *tables)
+        xc = L.f32c(x.detach())
+        P, levels = xc.shape[0], len(tables)
+        tabs = [L.f32c(t.detach()) for t in tables]
+        out = torch.empty(P, 2 * levels, device=xc.device)
+        L.check(L.lib().nerf_hashgrid_fwd(L.ptr(xc), P, L.ptr_array(tabs), L.int_array(res), L.int_array(sizes), levels,
+                                          L.ptr(out), None, None, L.stream_of(xc)), "nerf_hashgrid_fwd")
+        ctx.save_for_backward(xc)
+        ctx.meta = (tuple(res), tuple(sizes), [t.shape for t in tables])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (xc,) = ctx.saved_tensors
+        res, sizes, shapes = ctx.meta
+        g = L.f32c(d_out)
+        grads = [torch.zeros(s, device=xc.device) for s in shapes]
+        L.check(L.lib().nerf_hashgrid_bwd(L.ptr(xc), xc.shape[0], L.ptr(g), L.int_array(res), L.int_array(sizes),
+                                          len(res), L.ptr_array(grads), L.stream_of(xc)), "nerf_hashgrid_bwd")
+        return (None, None, None, *grads)
+
+
+def hashgrid_encode(x: torch.Tensor, tables: Sequence[torch.Tensor], res: Sequence[int]) -> torch.Tensor:
+    sizes = [int(t.shape[0]) for t in tables]
+    return _HashGrid.apply(x, list(res), sizes, *tables)
+
+
+def hashgrid_debug(x: torch.Tensor, tables: Sequence[torch.Tensor], res: Sequence[int]):
+    """Features plus the hashed row of every corner (int32 [levels,8,P]) and the
+    interpolation weights ([levels,P,3]) -- for parity checks."""
+    xc = L.f32c(x)
+    P, levels = xc.shape[0], len(tables)
+    tabs = [L.f32c(t.detach()) for t in tables]
+    sizes = [int(t.shape[0]) for t in tabs]
+    out = torch.empty(P, 2 * levels, device=xc.device)
+    idx = torch.empty(levels, 8, P, device=xc.device, dtype=torch.int32)
+    w = torch.empty(levels, P, 3, device=xc.device)
+    L.check(L.lib().nerf_hashgrid_fwd(L.ptr(xc), P, L.ptr_array(tabs), L.int_array(res), L.int_array(sizes), levels,
+                                      L.ptr(out), L.ptr(idx), L.ptr(w), L.stream_of(xc)), "nerf_hashgrid_fwd")
+    return out, idx, w
+
+
+# ----------------------------------------------------------- composite ----
+class _Composite(torch.autograd.Function):
+    """(rgb [R,N,3], sigma [R,N], z [R,N]) -> (colour [R,3], weights [R,N], depth [R])."""
+
+    @staticmethod
+    def forward(ctx, rgb, sigma, z, white_bkgd):
+        L.need_gpu(rgb, sigma, z)
+        rgb_c, sig_c, z_c = L.f32c(rgb.detach()), L.f32c(sigma.detach()), L.f32c(z.detach())
+        R, N = sig_c.shape
+        out = torch.empty(R, 3, device=rgb_c.device)
+        w = torch.empty(R, N, device=rgb_c.device)
+        depth = torch.empty(R, device=rgb_c.device)
+        L.check(L.lib().nerf_composite_fwd(L.ptr(rgb_c), L.ptr(sig_c), L.ptr(z_c), R, N, int(bool(white_bkgd)),
+                                           L.ptr(out), L.ptr(w), L.ptr(depth), L.stream_of(rgb_c)),
+                "nerf_composite_fwd")
+        ctx.save_for_backward(rgb_c, sig_c, z_c)
+        ctx.white = int(bool(white_bkgd))
+        ctx.set_materialize_grads(False)
+        return out, w, depth
+
+    @staticmethod
+    def backward(ctx, d_out, d_w, d_depth):
+        rgb_c, sig_c, z_c = ctx.saved_tensors
+        R, N = sig_c.shape
+        d_out = L.f32c(d_out) if d_out is not None else torch.zeros(R, 3, device=rgb_c.device)
+        d_w = L.f32c(d_w) if d_w is not None else None
+        d_depth = L.f32c(d_depth) if d_depth is not None else None
+        d_rgb = torch.empty_like(rgb_c)
+        d_sigma = torch.empty_like(sig_c)
+        L.check(L.lib().nerf_composite_bwd(L.ptr(rgb_c), L.ptr(sig_c), L.ptr(z_c), L.ptr(d_out), L.ptr(d_w),
+                                           L.ptr(d_depth), R, N, ctx.white, L.ptr(d_rgb), L.ptr(d_sigma),
+                                           L.stream_of(rgb_c)), "nerf_composite_bwd")
+        return d_rgb, d_sigma, None, None
+
+
+def composite(rgb, sigma, z, white_bkgd: bool = False):
+    """Alpha compositing over the last sample axis; leading axes are flattened to rays."""
+    lead = sigma.shape[:-1]
+    N = sigma.shape[-1]
+    out, w, depth = _Composite.apply(rgb.reshape(-1, N, 3), sigma.reshape(-1, N), z.reshape(-1, N), white_bkgd)
+    return out.view(*lead, 3), w.view(*lead, N), depth.view(*lead)
+
+
+# ---------------------------------------------------------- fused MLPs ----
+def _ceil32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+class _VanillaMLP(torch.autograd.Function):
+    """Fused 8x256 NeRF MLP: (x [P,3], dirs [P,3], 24 parameters) -> (rgb [P,3], sigma [P,1]).
+
+    Parameters arrive in the order W0,b0,...,W7,b7,Wsigma,bsigma,Wfeat,bfeat,
+    Wrgb0,brgb0,Wrgb2,brgb2.  Gradients are produced for the parameters only:
+    the sample positions and view directions are constants in every pipeline
+    of the reference.
+    """
+
+    @staticmethod
+    def forward(ctx, x, dirs, skip_h_first, *params):
+        assert len(params) == 24
+        L.need_gpu(x, dirs, *params)
+        lib = L.lib()
+        xc, dc = L.f32c(x.detach()), L.f32c(dirs.detach())
+        P = xc.shape[0]
+        assert xc.shape == (P, 3) and dc.shape == (P, 3), "x and view_dirs must be [N,3]"
+        dev = xc.device
+        ps = [L.f32c(p.detach()) for p in params]
+        st = L.stream_of(xc)
+        packed = torch.empty(lib.nerf_mlp_vanilla_pack_floats(), device=dev)
+        L.check(lib.nerf_mlp_vanilla_pack(L.ptr_array(ps), int(skip_h_first), L.ptr(packed), st), "nerf_mlp_vanilla_pack")
+        rgb = torch.empty(P, 3, device=dev)
+        sigma = torch.empty(P, 1, device=dev)
+        train = any(ctx.needs_input_grad[3:])
+        ws = torch.empty(_ceil32(P) * lib.nerf_mlp_vanilla_ws_floats_per_point(), device=dev) if train and P else None
+        L.check(lib.nerf_mlp_vanilla_fwd(L.ptr(xc), L.ptr(dc), P, L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), st),
+                "nerf_mlp_vanilla_fwd")
+        if train:
+            ctx.save_for_backward(packed, rgb, sigma, ws)
+            ctx.meta = (P, int(skip_h_first), [p.shape for p in params])
+        ctx.set_materialize_grads(False)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        packed, rgb, sigma, ws = ctx.saved_tensors
+        P, skip, shapes = ctx.meta
+        lib = L.lib()
+        dev = rgb.device
+        grads = [torch.zeros(s, device=dev) for s in shapes]
+        if P == 0:
+            return (None, None, None, *grads)
+        d_rgb = L.f32c(d_rgb) if d_rgb is not None else torch.zeros(P, 3, device=dev)
+        d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, 1, device=dev)
+        ws2 = torch.empty(_ceil32(P) * lib.nerf_mlp_vanilla_ws2_floats_per_point(), device=dev)
+        L.check(lib.nerf_mlp_vanilla_bwd(L.ptr(d_rgb), L.ptr(d_sigma), P, L.ptr(packed), L.ptr(rgb), L.ptr(sigma),
+                                         L.ptr(ws), L.ptr(ws2), skip, L.ptr_array(grads), L.stream_of(rgb)),
+                "nerf_mlp_vanilla_bwd")
+        return (None, None, None, *grads)
+
+
+def vanilla_mlp(x, dirs, params, skip_h_first: bool):
+    return _VanillaMLP.apply(x, dirs, bool(skip_h_first), *params)

@@ -1,0 +1,90 @@
+"""HIP encoders vs the CPU oracle and the reference's golden vectors."""
+import pytest
+import torch
+
+from conftest import T, load_golden, rel_err
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pe_golden_and_worst_case_arguments(dev):
+    from nerf_amd.utils.positional_encoding import PositionalEncoding
+    g = load_golden("g3_pe.npz")
+    x = T(g["x"]).to(dev)
+    pe10, pe4 = PositionalEncoding(10), PositionalEncoding(4)
+    assert pe10.output_dims == 63 and pe4.output_dims == 27
+    # tolerance 1e-6: arguments reach 2^9 * 6 = 3072 rad, so this also checks the range reduction
+    assert float((pe10(x).cpu() - T(g["pe10"])).abs().max()) < 1e-6
+    assert float((pe4(x).cpu() - T(g["pe4"])).abs().max()) < 1e-6
+    assert "freq_bands" not in pe10.state_dict()
+    gen = torch.Generator().manual_seed(3)
+    xb = (torch.rand(5000, 7, 3, generator=gen) * 12 - 6)
+    out = pe10(xb.to(dev))
+    assert out.shape == (5000, 7, 63)
+    assert float((out.cpu() - O.positional_encoding(xb, 10)).abs().max()) < 1e-6
+
+
+def _filled_tables(sizes, dev):
+    tabs = []
+    for l, n in enumerate(sizes):
+        r = torch.arange(int(n), dtype=torch.float64)
+        tabs.append(torch.stack([(torch.sin(r * (0.37 + 0.011 * l) + 1.3 * f + 0.5 * l) * 0.5).float()
+                                 for f in range(2)], dim=1).to(dev))
+    return tabs
+
+
+def test_hashgrid_indices_bit_exact_vs_golden(dev):
+    from nerf_amd import ops
+    g = load_golden("g4_hash.npz")
+    res = [int(v) for v in g["resolutions"]]
+    sizes = [int(v) for v in g["sizes"]]
+    tabs = _filled_tables(sizes, dev)
+    x = T(g["x"]).to(dev)
+    feats, idx, w = ops.hashgrid_debug(x, tabs, res)
+    assert torch.equal(idx.cpu(), T(g["idx"]))        # hash-table indices: bit-exact
+    assert torch.equal(w.cpu(), T(g["w"]))            # interpolation weights: bit-exact
+    assert float((feats.cpu() - T(g["feats"])).abs().max()) < 1e-6
+    # backward into the tables
+    tg = [t.clone().requires_grad_(True) for t in tabs]
+    out = ops.hashgrid_encode(x, tg, res)
+    assert torch.equal(out.detach(), feats)
+    (out * T(g["a"]).to(dev)).sum().backward()
+    for l, t in enumerate(tg):
+        # tolerance: atomics reorder float sums; 1e-3 relative is the contract
+        assert abs(float(t.grad.double().norm()) - g["grad_l2"][l]) <= 1e-5 * g["grad_l2"][l]
+        assert abs(float(t.grad.double().sum()) - g["grad_sum"][l]) <= 1e-4 * g["grad_l2"][l]
+        rows = T(g["grad_rows"][l]).long().to(dev)
+        assert torch.allclose(t.grad[rows].cpu(), T(g["grad_vals"][l]), rtol=1e-4, atol=1e-6)
+
+
+def test_hashgrid_module_state_dict_and_oracle(dev):
+    from nerf_amd.utils.hash_grid_encoder import HashGridEncoder
+    torch.manual_seed(0)
+    ref = O.HashGridOracle()
+    torch.manual_seed(0)
+    enc = HashGridEncoder()
+    sd, sd_ref = enc.state_dict(), ref.state_dict()
+    assert list(sd.keys()) == list(sd_ref.keys())
+    assert all(torch.equal(sd[k], sd_ref[k]) for k in sd)
+    assert sd["primes"].dtype == torch.int64
+    enc = enc.to(dev)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.rand(20000, 3, generator=gen) * 2.4 - 1.2   # includes negative and >1 coordinates
+    out = enc(x.to(dev))
+    out_ref = ref(x)
+    assert float((out.cpu() - out_ref).abs().max()) < 1e-8   # table entries are <= 1e-3
+    a = torch.randn(20000, 32, generator=gen)
+    (out * a.to(dev)).sum().backward()
+    (out_ref * a).sum().backward()
+    for e, r in zip(enc.embeddings, ref.embeddings):
+        assert rel_err(e.weight.grad.cpu(), r.weight.grad) < 1e-5
+    assert torch.equal(enc.hash_fn(torch.tensor([[3, 5, 7]], device=dev), 4096).cpu(),
+                       ref.primes.mul(torch.tensor([[3, 5, 7]])).sum(-1).bitwise_and(0xFFFFFFFF) % 4096)
+
+
+def test_hashgrid_empty_input(dev):
+    from nerf_amd import ops
+    tabs = _filled_tables([64, 64], dev)
+    out = ops.hashgrid_encode(torch.zeros(0, 3, device=dev), tabs, [4, 4])
+    assert out.shape == (0, 4)

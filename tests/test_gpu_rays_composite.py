@@ -1,0 +1,196 @@
+"""HIP kernels vs the CPU oracle and the reference's golden vectors: ray
+generation, stratified / hierarchical sampling, NDC, compositing."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden, rel_err
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_raygen_golden(dev):
+    from nerf_amd.Camera import Camera
+    g = load_golden("g1_raygen.npz")
+    H, W = [int(v) for v in g["robot_hw"]]
+    fx, fy, cx, cy = [float(v) for v in g["robot_intr"]]
+    c2w = T(g["robot_c2w"]).to(dev)
+    cam = Camera(eye=c2w[:, 3], target=None, focal=(fx, fy), H=H, W=W, c2w=c2w, pp=(cx, cy))
+    o, d = cam.get_rays()
+    assert o.shape == (H, W, 3) and d.shape == (H, W, 3)
+    assert torch.equal(o.cpu(), T(g["robot_o"]))
+    # tolerance: 2 ulp of a unit vector component (norm/divide rounding may differ from the CPU's)
+    assert float((d.cpu() - T(g["robot_d"])).abs().max()) <= 2.5e-7
+    cam = Camera(eye=torch.tensor([1.0, 1.0, 2.0], device=dev), target=torch.zeros(3, device=dev),
+                 focal=(100.0, 100.0), H=100, W=100)
+    assert torch.allclose(cam.c2w.cpu(), T(g["look_c2w"]), atol=1e-7)
+    o, d = cam.get_rays()
+    assert float((d.cpu() - T(g["look_d"])).abs().max()) <= 2.5e-7
+    # ray batch = gather of the full image
+    pix = torch.tensor([0, 99, 5050, 9999, 1234], device=dev, dtype=torch.int32)
+    ob, db = cam.get_ray_batch(pix)
+    assert torch.equal(db, d.view(-1, 3)[pix.long()]) and torch.equal(ob, o.view(-1, 3)[pix.long()])
+    H, W = [int(v) for v in g["llff_hw"]]
+    f = float(g["llff_f"][0])
+    c2w = T(g["llff_c2w"]).to(dev)
+    o, d = Camera(eye=c2w[:, 3], target=None, focal=(f, f), H=H, W=W, c2w=c2w).get_rays()
+    assert float((d.cpu() - T(g["llff_d"])).abs().max()) <= 2.5e-7
+
+
+def test_stratified_bit_exact_vs_golden(dev):
+    from nerf_amd.Camera import Camera
+    g = load_golden("g2_stratified.npz")
+    ro, rd = T(g["rays_o"]).to(dev), T(g["rays_d"]).to(dev)
+    for tag in "abc":
+        near, far, n = g[f"{tag}_cfg"]
+        pts, z = Camera.sample_points_along_rays(ro, rd, float(near), float(far), int(n), perturb=True,
+                                                 t_rand=T(g[f"{tag}_u"]).to(dev))
+        assert torch.equal(z.cpu(), T(g[f"{tag}_z"])), tag       # bit-exact depths
+        assert torch.equal(pts.cpu(), T(g[f"{tag}_pts"])), tag   # and points
+        pts0, z0 = Camera.sample_points_along_rays(ro, rd, float(near), float(far), int(n), perturb=False)
+        assert torch.equal(z0.cpu(), T(g[f"{tag}_z0"])) and torch.equal(pts0.cpu(), T(g[f"{tag}_pts0"]))
+    # default perturbation draws its own uniforms and stays inside the strata
+    pts, z = Camera.sample_points_along_rays(ro, rd, 2.0, 6.0, 64)
+    assert bool((z[..., 1:] >= z[..., :-1]).all()) and float(z.min()) >= 2.0 and float(z.max()) <= 6.0
+
+
+def test_raygen_sample_fused_equals_two_step(dev):
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(1)
+    H = W = 800
+    f = 0.5 * 800 / np.tan(0.5 * 0.6911112)
+    c2w = O.look_at_camera(torch.tensor([2.0, -3.0, 1.8]), torch.zeros(3), torch.tensor([0.0, 0.0, 1.0])).to(dev)
+    pix = torch.randperm(H * W, generator=gen)[:4096].to(torch.int32).to(dev)
+    u = torch.rand(4096, 64, generator=gen).to(dev)
+    z_lin = torch.linspace(2.0, 6.0, 64).to(dev)
+    o, d, z, pts = ops.raygen_sample(c2w, f, f, 400.0, 400.0, H, W, pix, z_lin, u)
+    o2, d2 = ops.raygen(c2w, f, f, 400.0, 400.0, H, W, pix)
+    z2, pts2 = ops.stratified_sample(o2, d2, z_lin, u)
+    assert torch.equal(o, o2) and torch.equal(d, d2) and torch.equal(z, z2) and torch.equal(pts, pts2)
+    # oracle on the same rays and uniforms: depths bit-exact
+    pts_o, z_o = O.sample_points_along_rays(o.cpu(), d.cpu(), 2.0, 6.0, 64, u.cpu())
+    assert torch.equal(z.cpu(), z_o) and torch.equal(pts.cpu(), pts_o)
+
+
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (17, 5), (3, 1), (100, 200), (256, 768)])
+def test_pdf_sample_indices_bit_exact(dev, Nc, Nf):
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(100 + Nc)
+    R = 257
+    o = torch.randn(R, 3, generator=gen)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    z = torch.sort(torch.rand(R, Nc, generator=gen) * 4 + 2, dim=-1).values
+    w = torch.rand(R, Nc, generator=gen) ** 6
+    w[0] = 0.0
+    if Nc > 4:
+        w[1, 1:-1] = 0.0
+        w[1, Nc // 2] = 1.0
+    u = torch.rand(R, Nf, generator=gen)
+    u[2, 0] = 0.0
+    zf_o, idx_o, zall_o = O.sample_pdf(z, w, u)
+    zf, idx, z_all, pts = ops.pdf_sample(o.to(dev), d.to(dev), z.to(dev), w.to(dev), u.to(dev), want_idx=True)
+    assert torch.equal(idx.cpu(), idx_o)          # sample indices: bit-exact
+    assert torch.equal(zf.cpu(), zf_o)            # same float ops in the same order
+    assert torch.equal(z_all.cpu(), zall_o)
+    pts_o = o[:, None, :] + d[:, None, :] * zall_o[..., None]
+    assert torch.equal(pts.cpu(), pts_o)
+
+
+def test_pdf_sample_rejects_bad_sizes(dev):
+    from nerf_amd import ops
+    from nerf_amd._lib import NerfHipError
+    z = torch.zeros(4, 2, device=dev)
+    with pytest.raises(NerfHipError):
+        ops.pdf_sample(torch.zeros(4, 3, device=dev), torch.zeros(4, 3, device=dev), z, z, torch.zeros(4, 8, device=dev))
+
+
+def test_ndc_rays(dev):
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    o = torch.randn(1000, 3, generator=gen) * 0.3
+    d = torch.randn(1000, 3, generator=gen)
+    d[:, 2] = -d[:, 2].abs() - 0.5
+    o2, d2 = ops.ndc_rays(378, 504, 415.1, 1.0, o.to(dev), d.to(dev))
+    oo, dd = O.ndc_rays(378, 504, 415.1, 1.0, o, d)
+    assert torch.allclose(o2.cpu(), oo, rtol=1e-6, atol=1e-6) and torch.allclose(d2.cpu(), dd, rtol=1e-6, atol=1e-6)
+
+
+def _composite_case(dev, tag, wb, g):
+    from nerf_amd.Camera import Camera
+    r = T(g[f"{tag}_rgb"]).to(dev).requires_grad_(True)
+    s = T(g[f"{tag}_sigma"]).to(dev).requires_grad_(True)
+    z = T(g[f"{tag}_z"]).to(dev)
+    c, w = Camera.volume_render(r, s, z, white_bkgd=bool(wb))
+    k = f"{tag}{wb}"
+    assert float((c.detach().cpu() - T(g[f"{k}_c"])).abs().max()) < 1e-6
+    assert float((w.detach().cpu() - T(g[f"{k}_w"])).abs().max()) < 1e-6
+    loss = torch.nn.functional.mse_loss(c, T(g[f"{tag}_tgt"]).to(dev)) + 0.05 * (1 - w.sum(dim=-1)).abs().mean()
+    loss.backward()
+    assert abs(float(loss) - float(g[f"{k}_loss"])) < 1e-6
+    assert torch.allclose(r.grad.cpu(), T(g[f"{k}_drgb"]), rtol=1e-4, atol=1e-8)
+    assert torch.allclose(s.grad.cpu(), T(g[f"{k}_dsigma"]), rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+@pytest.mark.parametrize("wb", [0, 1])
+def test_composite_golden(dev, tag, wb):
+    _composite_case(dev, tag, wb, load_golden("g6_composite.npz"))
+
+
+@pytest.mark.parametrize("N", [2, 3, 63, 64, 65, 128, 192, 200, 513, 1024])
+def test_composite_vs_oracle_sizes(dev, N):
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(N)
+    R = 131
+    rgb = torch.rand(R, N, 3, generator=gen)
+    sigma = torch.rand(R, N, generator=gen) * (30.0 / N) * 4
+    z = torch.sort(torch.rand(R, N, generator=gen) * 4 + 2, dim=-1).values
+    dC = torch.randn(R, 3, generator=gen)
+    dW = torch.randn(R, N, generator=gen)
+    dD = torch.randn(R, generator=gen)
+    for wb in (False, True):
+        r_o = rgb.clone().requires_grad_(True)
+        s_o = sigma.clone().requires_grad_(True)
+        c_o, w_o = O.volume_render(r_o, s_o, z, wb)
+        d_o = O.depth(w_o, z)
+        ((c_o * dC).sum() + (w_o * dW).sum() + (d_o * dD).sum()).backward()
+        r_g = rgb.to(dev).requires_grad_(True)
+        s_g = sigma.to(dev).requires_grad_(True)
+        c_g, w_g, d_g = ops.composite(r_g, s_g, z.to(dev), wb)
+        ((c_g * dC.to(dev)).sum() + (w_g * dW.to(dev)).sum() + (d_g * dD.to(dev)).sum()).backward()
+        # tolerance: 1e-3 absolute is the contract; the kernels land near 1e-6
+        # (a 1024-factor transmittance product reassociated by the wave scan drifts by a few 1e-6)
+        assert float((c_g.detach().cpu() - c_o.detach()).abs().max()) < 2e-5
+        assert float((w_g.detach().cpu() - w_o.detach()).abs().max()) < 1e-5
+        assert float((d_g.detach().cpu() - d_o.detach()).abs().max()) < 1e-4
+        assert rel_err(r_g.grad.cpu(), r_o.grad) < 1e-5
+        assert rel_err(s_g.grad.cpu(), s_o.grad) < 1e-5
+
+
+def test_composite_full_size_properties(dev):
+    """4096 rays x 192 samples: weights are a sub-probability vector and a
+    constant colour composites to itself times the accumulated opacity."""
+    from nerf_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    R, N = 4096, 192
+    sigma = (torch.rand(R, N, generator=gen) * 0.5).to(dev)
+    z = torch.sort(torch.rand(R, N, generator=gen) * 4 + 2, dim=-1).values.to(dev)
+    rgb = torch.full((R, N, 3), 0.25, device=dev)
+    c, w, _ = ops.composite(rgb, sigma, z, False)
+    acc = w.sum(-1)
+    assert bool((w >= 0).all()) and float(acc.max()) <= 1.0 + 1e-5
+    assert torch.allclose(c, 0.25 * acc[:, None].expand(R, 3), atol=1e-5)
+    # linearity in colour
+    rgb2 = torch.rand(R, N, 3, generator=gen).to(dev)
+    c1, _, _ = ops.composite(rgb2, sigma, z, False)
+    c2, _, _ = ops.composite(2 * rgb2, sigma, z, False)
+    assert torch.allclose(c2, 2 * c1, atol=1e-5)
+
+
+def test_composite_rejects_too_many_samples(dev):
+    from nerf_amd import ops
+    from nerf_amd._lib import NerfHipError
+    with pytest.raises(NerfHipError):
+        ops.composite(torch.zeros(2, 1025, 3, device=dev), torch.zeros(2, 1025, device=dev),
+                      torch.zeros(2, 1025, device=dev))
