@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec of one NeRF training step (forward + backward +
+Adam) on synthetic Blender-lego-shaped ray batches, 64 coarse + 128 fine
+samples, vanilla 8x256 MLPs (coarse and fine), fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run, one rank per GPU: every rank
+renders its own 4096-ray batch (rays are independent, weak scaling) and the
+parameter gradients are averaged with one RCCL all-reduce per step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 800
+FOCAL = 0.5 * 800 / math.tan(0.5 * 0.6911112)   # Blender lego camera_angle_x
+NEAR, FAR = 2.0, 6.0
+N_COARSE, N_FINE = 64, 128
+# Algorithmic FLOPs per point evaluation of the 8x256 MLP (593,408 MACs forward):
+FLOP_FWD = 2 * 593408
+FLOP_BWD_DATA = 2 * (593408 - 63 * 256 - 63 * 256 - 27 * 128)   # no gradient into the encodings
+FLOP_WGRAD = 2 * 593408
+PEAK_F32_MATRIX_TFLOPS = 157.3
+
+
+def lego_pose(seed: int) -> torch.Tensor:
+    """Look-at pose on the radius-4.03 sphere of the Blender scenes (reference camera convention)."""
+    from nerf_amd.Camera import look_at_camera
+    g = torch.Generator().manual_seed(seed)
+    th = float(torch.rand(1, generator=g)) * 2 * math.pi
+    ph = math.radians(30.0)
+    eye = 4.03 * torch.tensor([math.cos(th) * math.cos(ph), math.sin(th) * math.cos(ph), math.sin(ph)])
+    # the reference's rays leave along -forward: aim the look-at at the mirrored point
+    return look_at_camera(eye, 2 * eye, torch.tensor([0.0, 0.0, 1.0]))
+
+
+def make_batch(rank: int, rays: int, dev):
+    g = torch.Generator().manual_seed(1 + rank)
+    pix = torch.randperm(H * W, generator=g)[:rays].to(torch.int32)
+    g2 = torch.Generator().manual_seed(2 + 1000 * rank)
+    u_c = torch.rand(rays, N_COARSE, generator=g2)
+    u_f = torch.rand(rays, N_FINE, generator=g2)
+    g3 = torch.Generator().manual_seed(3 + 1000 * rank)
+    gt = torch.rand(rays, 3, generator=g3)
+    return lego_pose(0).to(dev), pix.to(dev), u_c.to(dev), u_f.to(dev), gt.to(dev)
+
+
+def gpu_main(args):
+    import torch.distributed as dist
+    from nerf_amd import ops
+    from nerf_amd.models.NeRF import NeRF
+    from nerf_amd.render import nerf_loss, render_rays
+    from nerf_amd.dist import GradAverager
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(0)
+    coarse = NeRF().to(dev)
+    torch.manual_seed(1)
+    fine = NeRF().to(dev)
+    params = list(coarse.parameters()) + list(fine.parameters())
+    opt = torch.optim.Adam(params, lr=5e-4)
+    averager = GradAverager(params) if world > 1 else None
+    c2w, pix, u_c, u_f, gt = make_batch(rank, args.rays, dev)
+
+    def step():
+        o, d = ops.raygen(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix)
+        out = render_rays(coarse, o, d, NEAR, FAR, N_COARSE, perturb=True, t_rand=u_c, white_bkgd=True,
+                          fine_model=fine, n_importance=N_FINE, u_fine=u_f)
+        loss = nerf_loss(out, gt)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if averager is not None:
+            averager.average()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+
+    result = None
+    if rank == 0:
+        roof = kernel_roofline(coarse, args.rays, dev)
+        result = {
+            "metric": "rays/sec fwd+bwd (lego 800x800, 64 coarse + 128 fine)",
+            "value": world * args.rays * args.steps / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "vanilla NeRF 8x256 coarse+fine, Blender-lego-shaped 800x800 camera, "
+                                   "64 coarse + 128 fine samples, %d-ray batch per GPU, one training step "
+                                   "(ray-gen, sampling, MLPs, compositing, backward, Adam)" % args.rays,
+                       "rays_per_gpu": args.rays, "parallelism": "ray-sharded dp%d" % world,
+                       "final_loss": final_loss},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_rays)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def _time_kernel(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def kernel_roofline(model, rays, dev):
+    """Time the three MLP kernels alone (HIP events on the launch stream) at the
+    fine-pass size and report the one that takes most of the step."""
+    from nerf_amd import ops
+    P = rays * (N_COARSE + N_FINE)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(P, 3, generator=g) * 4 - 2).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(rays, 3, generator=g), dim=-1).to(dev)
+    d_rgb = torch.randn(P, 3, generator=g).to(dev)
+    d_sig = torch.randn(P, 1, generator=g).to(dev)
+    params = model._params()
+    packed = ops.vanilla_pack(params, False)
+    rgb, sigma, ws = ops.vanilla_fwd_raw(x, d, N_COARSE + N_FINE, packed, True)
+    ws2 = ops.vanilla_ws2(P, dev)
+    grads = ops.zero_grads_like([p.shape for p in params], dev)
+    lib_ws = ws  # keep alive
+
+    def fwd():
+        from nerf_amd import _lib as L
+        L.check(L.lib().nerf_mlp_vanilla_fwd(L.ptr(x), L.ptr(d), N_COARSE + N_FINE, P, L.ptr(packed), L.ptr(rgb),
+                                             L.ptr(sigma), L.ptr(lib_ws), L.stream_of(x)), "fwd")
+
+    t_fwd = _time_kernel(fwd)
+    t_bd = _time_kernel(lambda: ops.vanilla_bwd_raw(d_rgb, d_sig, packed, rgb, sigma, ws, ws2, False, grads, phases=1))
+    t_wg = _time_kernel(lambda: ops.vanilla_bwd_raw(d_rgb, d_sig, packed, rgb, sigma, ws, ws2, False, grads, phases=2))
+    kernels = {
+        "vanilla_fwd_kernel": (t_fwd, FLOP_FWD),
+        "vanilla_bwd_data_kernel": (t_bd, FLOP_BWD_DATA),
+        "wgrad_kernel": (t_wg, FLOP_WGRAD),
+    }
+    name = max(kernels, key=lambda k: kernels[k][0])
+    t, flop = kernels[name]
+    achieved = flop * P / t / 1e12
+    return {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None, "points_per_launch": P,
+            "all_kernels_tflops": {k: v[1] * P / v[0] / 1e12 for k, v in kernels.items()},
+            "all_kernels_ms": {k: v[0] * 1e3 for k, v in kernels.items()}}
+
+
+def cpu_baseline(rays):
+    """The reference's op sequence (CPU PyTorch restatement in oracle/) on the host
+    cores: same camera, same sampling, two 8x256 MLPs evaluated in 2048-point
+    chunks, compositing, loss, backward, Adam -- on a bounded ray sample."""
+    from oracle import nerf_oracle as O
+    threads = torch.get_num_threads()
+    torch.manual_seed(0)
+    coarse = O.NeRFOracle()
+    torch.manual_seed(1)
+    fine = O.NeRFOracle()
+    opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
+    g = torch.Generator().manual_seed(1)
+    pix = torch.randperm(H * W, generator=g)[:rays]
+    g2 = torch.Generator().manual_seed(2)
+    u_c = torch.rand(rays, N_COARSE, generator=g2)
+    u_f = torch.rand(rays, N_FINE, generator=g2)
+    gt = torch.rand(rays, 3, generator=torch.Generator().manual_seed(3))
+    c2w = lego_pose(0)
+
+    def step():
+        o, d = O.get_rays(c2w, (FOCAL, FOCAL), H, W)
+        o, d = o.reshape(-1, 3)[pix], d.reshape(-1, 3)[pix]
+        c_map, w, z, fine_out = O.render_rays(coarse, o, d, NEAR, FAR, N_COARSE, t_rand=u_c, chunk=2048,
+                                              white_bkgd=True, fine_model=fine, u_fine=u_f)
+        loss = torch.nn.functional.mse_loss(c_map, gt) + torch.nn.functional.mse_loss(fine_out[0], gt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    return {"value": rays / med, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": "%d-ray batch of the same workload (64c+128f, two 8x256 MLPs, fwd+bwd+Adam), "
+                      "median of 3 steps after 1 warm-up, torch %s CPU" % (rays, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--cpu-rays", type=int, default=512, help="ray sample of the CPU baseline")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and world == 1:
+        # convenience: re-launch under torch.distributed.run (nothing has touched the GPU yet)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    gpu_main(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -132,16 +132,21 @@ int nerf_mlp_vanilla_pack(const float* const* params, int skip_h_first, float* p
  * and of the backward's own scratch (per-layer pre-activation gradients). */
 size_t nerf_mlp_vanilla_ws_floats_per_point(void);
 size_t nerf_mlp_vanilla_ws2_floats_per_point(void);
-/* x [P,3], dirs [P,3] -> rgb [P,3], sigma [P].  ws: workspace of
- * ceil32(P)*ws_floats_per_point floats, or NULL for inference. */
-int nerf_mlp_vanilla_fwd(const float* x, const float* dirs, int64_t P, const float* packed,
-                         float* rgb, float* sigma, float* ws, void* stream);
-/* d_rgb [P,3], d_sigma [P] -> parameter gradients, ACCUMULATED into `grads`
- * (host array of 24 device pointers, same order/shapes as params).
- * ws is the forward's workspace; ws2: ceil32(P)*ws_floats_per_point floats. */
+/* x [P,3], dirs [ceil(P/dirs_div),3] -> rgb [P,3], sigma [P].  Point p uses
+ * direction row p/dirs_div: dirs_div = 1 is the reference's per-point view_dirs,
+ * dirs_div = samples-per-ray lets one row per ray serve all its samples (what
+ * render_image expands by hand, src/train_nerf_llff.py:42-47).  ws: workspace of
+ * ceil32(P)*ws_floats_per_point floats, or NULL for inference (nothing saved). */
+int nerf_mlp_vanilla_fwd(const float* x, const float* dirs, int dirs_div, int64_t P,
+                         const float* packed, float* rgb, float* sigma, float* ws, void* stream);
+/* d_rgb [P,3], d_sigma [P] -> parameter gradients, ACCUMULATED (float atomics)
+ * into `grads` (host array of 24 device pointers, same order/shapes as params;
+ * zero them first).  ws is the forward's workspace; ws2: ceil32(P) *
+ * ws2_floats_per_point floats of scratch.  phases: bit 0 runs the backward-data
+ * chain (fills ws2), bit 1 the weight-gradient kernels (read ws and ws2); pass 3. */
 int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, int64_t P, const float* packed,
                          const float* rgb, const float* sigma, float* ws, float* ws2,
-                         int skip_h_first, float* const* grads, void* stream);
+                         int skip_h_first, float* const* grads, int phases, void* stream);
 
 #ifdef __cplusplus
 }

@@ -74,7 +74,7 @@ template <bool SAVE>
 __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dirs,
                                                           long long P, const float* __restrict__ pk,
                                                           float* __restrict__ rgb, float* __restrict__ sigma,
-                                                          float* __restrict__ ws) {
+                                                          float* __restrict__ ws, int dirs_div) {
     TileIdx ix;
     if (!tile_index(P, ix)) return;
     const int lane = ix.lane, h = ix.h;
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     if (SAVE) store_row<8>(ws + ix.P32 * vw::FEAT + ix.gp * 256, acc, h, true);
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
-    pe_tiles<1>(de, dirs[3 * ix.lp], dirs[3 * ix.lp + 1], dirs[3 * ix.lp + 2], 4, h);
+    const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
+    pe_tiles<1>(de, dirs[3 * dr], dirs[3 * dr + 1], dirs[3 * dr + 2], 4, h);
     if (SAVE) store_row<1>(ws + ix.P32 * vw::DE + ix.gp * 32, de, h, true);
     f32x16 hr[4];
     fill_rows<4>(hr, pk + vp::S_B1, h);
@@ -264,32 +265,35 @@ extern "C" int nerf_mlp_vanilla_pack(const float* const* params, int skip_h_firs
     return launch_pack(J, packed, (hipStream_t)stream);
 }
 
-extern "C" int nerf_mlp_vanilla_fwd(const float* x, const float* dirs, int64_t P, const float* packed, float* rgb,
-                                    float* sigma, float* ws, void* stream) {
+extern "C" int nerf_mlp_vanilla_fwd(const float* x, const float* dirs, int dirs_div, int64_t P, const float* packed,
+                                    float* rgb, float* sigma, float* ws, void* stream) {
     if (P == 0) return NERF_OK;
     NERF_REQUIRE(x && dirs && packed && rgb && sigma, "nerf_mlp_vanilla_fwd: null pointer");
-    NERF_REQUIRE(P >= 0, "nerf_mlp_vanilla_fwd: P=%lld", (long long)P);
+    NERF_REQUIRE(P >= 0 && dirs_div >= 1, "nerf_mlp_vanilla_fwd: P=%lld dirs_div=%d", (long long)P, dirs_div);
     const dim3 grid((unsigned)ceil_div(P, 128)), block(256);
     if (ws)
         hipLaunchKernelGGL(vanilla_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, dirs, (long long)P, packed, rgb,
-                           sigma, ws);
+                           sigma, ws, dirs_div);
     else
         hipLaunchKernelGGL(vanilla_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, dirs, (long long)P, packed,
-                           rgb, sigma, ws);
+                           rgb, sigma, ws, dirs_div);
     return check_launch("nerf_mlp_vanilla_fwd");
 }
 
 extern "C" int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, int64_t P, const float* packed,
                                     const float* rgb, const float* sigma, float* ws, float* ws2, int skip_h_first,
-                                    float* const* grads, void* stream) {
+                                    float* const* grads, int phases, void* stream) {
     if (P == 0) return NERF_OK;
     NERF_REQUIRE(d_rgb && d_sigma && packed && rgb && sigma && ws && ws2 && grads, "nerf_mlp_vanilla_bwd: null pointer");
     for (int i = 0; i < NERF_VANILLA_NPARAM; ++i) NERF_REQUIRE(grads[i], "nerf_mlp_vanilla_bwd: gradient %d is null", i);
     NERF_REQUIRE(P >= 0, "nerf_mlp_vanilla_bwd: P=%lld", (long long)P);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(vanilla_bwd_data_kernel, dim3((unsigned)ceil_div(P, 128)), dim3(256), 0, st, d_rgb, d_sigma,
-                       (long long)P, packed, rgb, sigma, ws, ws2);
-    if (int rc = check_launch("nerf_mlp_vanilla_bwd(data)")) return rc;
+    if (phases & 1) {
+        hipLaunchKernelGGL(vanilla_bwd_data_kernel, dim3((unsigned)ceil_div(P, 128)), dim3(256), 0, st, d_rgb, d_sigma,
+                           (long long)P, packed, rgb, sigma, ws, ws2);
+        if (int rc = check_launch("nerf_mlp_vanilla_bwd(data)")) return rc;
+    }
+    if (!(phases & 2)) return NERF_OK;
 
     const long long P32 = (P + 31) / 32 * 32;
     auto H = [&](int l) { return ws + P32 * (vw::H + 256 * l); };

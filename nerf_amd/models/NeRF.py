@@ -7,6 +7,8 @@ from ..utils.positional_encoding import PositionalEncoding
 
 
 class NeRF(nn.Module):
+    _skip_h_first = False  # layer-4 input is [x_enc | h]
+
     """Same constructor, parameter names/shapes/creation order (hence the same
     seeded initial weights and state dict) as src/models/NeRF.py:16-65.
 

@@ -198,8 +198,54 @@ def _ceil32(n: int) -> int:
     return (n + 31) // 32 * 32
 
 
+def vanilla_pack(params, skip_h_first: bool) -> torch.Tensor:
+    """Re-order the 24 parameter tensors into the MFMA operand layout (one launch)."""
+    lib = L.lib()
+    ps = [L.f32c(p.detach()) for p in params]
+    packed = torch.empty(lib.nerf_mlp_vanilla_pack_floats(), device=ps[0].device)
+    L.check(lib.nerf_mlp_vanilla_pack(L.ptr_array(ps), int(skip_h_first), L.ptr(packed), L.stream_of(packed)),
+            "nerf_mlp_vanilla_pack")
+    return packed
+
+
+def vanilla_fwd_raw(x, dirs, dirs_div: int, packed, save: bool):
+    """x [P,3], dirs [ceil(P/dirs_div),3] -> rgb [P,3], sigma [P,1], workspace (or None)."""
+    lib = L.lib()
+    P = x.shape[0]
+    dev = x.device
+    rgb = torch.empty(P, 3, device=dev)
+    sigma = torch.empty(P, 1, device=dev)
+    ws = torch.empty(_ceil32(P) * lib.nerf_mlp_vanilla_ws_floats_per_point(), device=dev) if save and P else None
+    L.check(lib.nerf_mlp_vanilla_fwd(L.ptr(x), L.ptr(dirs), int(dirs_div), P, L.ptr(packed), L.ptr(rgb), L.ptr(sigma),
+                                     L.ptr(ws), L.stream_of(x)), "nerf_mlp_vanilla_fwd")
+    return rgb, sigma, ws
+
+
+def vanilla_bwd_raw(d_rgb, d_sigma, packed, rgb, sigma, ws, ws2, skip_h_first: bool, grads, phases: int = 3):
+    """Accumulate the parameter gradients into ``grads`` (24 zeroed tensors)."""
+    P = rgb.shape[0]
+    L.check(L.lib().nerf_mlp_vanilla_bwd(L.ptr(d_rgb), L.ptr(d_sigma), P, L.ptr(packed), L.ptr(rgb), L.ptr(sigma),
+                                         L.ptr(ws), L.ptr(ws2), int(skip_h_first), L.ptr_array(grads), int(phases),
+                                         L.stream_of(rgb)), "nerf_mlp_vanilla_bwd")
+
+
+def vanilla_ws2(P: int, device) -> torch.Tensor:
+    return torch.empty(_ceil32(P) * L.lib().nerf_mlp_vanilla_ws2_floats_per_point(), device=device)
+
+
+def zero_grads_like(shapes, device):
+    """One zeroed flat buffer viewed as per-parameter gradients (a single memset)."""
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
+    flat = torch.zeros(sum(sizes), device=device)
+    out, off = [], 0
+    for s, n in zip(shapes, sizes):
+        out.append(flat[off:off + n].view(s))
+        off += n
+    return out
+
+
 class _VanillaMLP(torch.autograd.Function):
-    """Fused 8x256 NeRF MLP: (x [P,3], dirs [P,3], 24 parameters) -> (rgb [P,3], sigma [P,1]).
+    """Fused 8x256 NeRF MLP: (x [P,3], dirs, 24 parameters) -> (rgb [P,3], sigma [P,1]).
 
     Parameters arrive in the order W0,b0,...,W7,b7,Wsigma,bsigma,Wfeat,bfeat,
     Wrgb0,brgb0,Wrgb2,brgb2.  Gradients are produced for the parameters only:
@@ -208,27 +254,19 @@ class _VanillaMLP(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, dirs, skip_h_first, *params):
+    def forward(ctx, x, dirs, dirs_div, skip_h_first, *params):
         assert len(params) == 24
         L.need_gpu(x, dirs, *params)
-        lib = L.lib()
         xc, dc = L.f32c(x.detach()), L.f32c(dirs.detach())
         P = xc.shape[0]
-        assert xc.shape == (P, 3) and dc.shape == (P, 3), "x and view_dirs must be [N,3]"
-        dev = xc.device
-        ps = [L.f32c(p.detach()) for p in params]
-        st = L.stream_of(xc)
-        packed = torch.empty(lib.nerf_mlp_vanilla_pack_floats(), device=dev)
-        L.check(lib.nerf_mlp_vanilla_pack(L.ptr_array(ps), int(skip_h_first), L.ptr(packed), st), "nerf_mlp_vanilla_pack")
-        rgb = torch.empty(P, 3, device=dev)
-        sigma = torch.empty(P, 1, device=dev)
-        train = any(ctx.needs_input_grad[3:])
-        ws = torch.empty(_ceil32(P) * lib.nerf_mlp_vanilla_ws_floats_per_point(), device=dev) if train and P else None
-        L.check(lib.nerf_mlp_vanilla_fwd(L.ptr(xc), L.ptr(dc), P, L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), st),
-                "nerf_mlp_vanilla_fwd")
+        assert xc.shape == (P, 3), "x must be [N,3]"
+        assert dc.shape == ((P + dirs_div - 1) // dirs_div, 3), "view_dirs must be [N,3] (or one row per ray)"
+        packed = vanilla_pack(params, skip_h_first)
+        train = any(ctx.needs_input_grad[4:])
+        rgb, sigma, ws = vanilla_fwd_raw(xc, dc, dirs_div, packed, train)
         if train:
             ctx.save_for_backward(packed, rgb, sigma, ws)
-            ctx.meta = (P, int(skip_h_first), [p.shape for p in params])
+            ctx.meta = (P, bool(skip_h_first), [p.shape for p in params])
         ctx.set_materialize_grads(False)
         return rgb, sigma
 
@@ -236,19 +274,15 @@ class _VanillaMLP(torch.autograd.Function):
     def backward(ctx, d_rgb, d_sigma):
         packed, rgb, sigma, ws = ctx.saved_tensors
         P, skip, shapes = ctx.meta
-        lib = L.lib()
         dev = rgb.device
-        grads = [torch.zeros(s, device=dev) for s in shapes]
+        grads = zero_grads_like(shapes, dev)
         if P == 0:
-            return (None, None, None, *grads)
+            return (None, None, None, None, *grads)
         d_rgb = L.f32c(d_rgb) if d_rgb is not None else torch.zeros(P, 3, device=dev)
         d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, 1, device=dev)
-        ws2 = torch.empty(_ceil32(P) * lib.nerf_mlp_vanilla_ws2_floats_per_point(), device=dev)
-        L.check(lib.nerf_mlp_vanilla_bwd(L.ptr(d_rgb), L.ptr(d_sigma), P, L.ptr(packed), L.ptr(rgb), L.ptr(sigma),
-                                         L.ptr(ws), L.ptr(ws2), skip, L.ptr_array(grads), L.stream_of(rgb)),
-                "nerf_mlp_vanilla_bwd")
-        return (None, None, None, *grads)
+        vanilla_bwd_raw(d_rgb, d_sigma, packed, rgb, sigma, ws, vanilla_ws2(P, dev), skip, grads)
+        return (None, None, None, None, *grads)
 
 
-def vanilla_mlp(x, dirs, params, skip_h_first: bool):
-    return _VanillaMLP.apply(x, dirs, bool(skip_h_first), *params)
+def vanilla_mlp(x, dirs, params, skip_h_first: bool, dirs_div: int = 1):
+    return _VanillaMLP.apply(x, dirs, int(dirs_div), bool(skip_h_first), *params)
