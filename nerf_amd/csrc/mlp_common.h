@@ -26,24 +26,36 @@ __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16
                                       int lane) {
     static_assert(OT % 4 == 0, "OT must be a multiple of 4");
     constexpr int V = OT / 4;
+    constexpr int S = KT * 16;       // k-steps; one step = OT MFMAs sharing one B register
+    constexpr int D = S < 4 ? S : 4;  // steps of weight prefetch kept in flight (L2 latency >> one step)
     const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane * V;
+    float4 ring[D][V];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int s = 0; s < D; ++s)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float a[OT];
+        for (int v = 0; v < V; ++v) ring[s][v] = w4[(size_t)(s * 64) * V + v];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const float4 t = w4[(size_t)((kt * 16 + r) * 64) * V + v];
-                a[4 * v + 0] = t.x;
-                a[4 * v + 1] = t.y;
-                a[4 * v + 2] = t.z;
-                a[4 * v + 3] = t.w;
-            }
-            const float b = in[kt][r];
+    for (int s = 0; s < S; ++s) {
+        float a[OT];
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ot], b, acc[ot], 0, 0, 0);
+        for (int v = 0; v < V; ++v) {
+            const float4 t = ring[s % D][v];
+            a[4 * v + 0] = t.x;
+            a[4 * v + 1] = t.y;
+            a[4 * v + 2] = t.z;
+            a[4 * v + 3] = t.w;
         }
+        if (s + D < S) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) ring[s % D][v] = w4[(size_t)((s + D) * 64) * V + v];
+        }
+        // Pin the order "issue the prefetch, then this step's MFMAs": left alone the
+        // scheduler sinks every load to just before its use and exposes its latency.
+        __builtin_amdgcn_sched_barrier(0);
+        const float b = in[s / 16][s % 16];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ot], b, acc[ot], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -193,14 +205,15 @@ int launch_pack(const PackJobs& jobs, float* packed, hipStream_t stream);
 // Weight-gradient work list: dW[n][col_off + k] += sum_p dY[p][n] * X[p][k].
 // ---------------------------------------------------------------------------
 struct WgradPart {
-    const float* dY;   // [P32][ldY], columns n_off .. n_off + N
+    const float* dY;   // [P32][ldY], columns 0 .. N
     const float* X;    // [P32][ldX], columns 0 .. 32*KT
+    const float* X2;   // optional second input block [P32][ldX2], columns 0 .. 32*KT2
     float* dW;         // nn.Linear gradient [N][ldW]
     float* dbias;      // [N] or null
-    int ldY, ldX, ldW;
-    int col_off;       // first gradient column written
-    int k_valid;       // columns >= k_valid are padding and are not written
-    int shape;         // index into the (NTW, KT) instantiation list
+    int ldY, ldX, ldX2, ldW;
+    int col_off, col_off2;   // first gradient column written by the X / X2 tiles
+    int k_valid, k_valid2;   // columns >= k_valid within a block are padding and are not written
+    int shape;         // index into the (NTW, KT, KT2) instantiation list
     int slabs;         // point slabs this part is split into
     int first_block;   // prefix sum of slabs
 };
@@ -245,10 +258,11 @@ inline PackJob pack_copy_job(const float* src, int dst, int count) {
     return j;
 }
 inline WgradPart wgrad_part_desc(const float* dY, int ldY, const float* X, int ldX, float* dW, int ldW, int col_off,
-                                 int k_valid, float* dbias, int shape) {
+                                 int k_valid, float* dbias, int shape, const float* X2 = nullptr, int ldX2 = 0,
+                                 int col_off2 = 0, int k_valid2 = 0) {
     WgradPart p{};
     p.dY = dY; p.ldY = ldY; p.X = X; p.ldX = ldX; p.dW = dW; p.ldW = ldW; p.col_off = col_off; p.k_valid = k_valid;
-    p.dbias = dbias; p.shape = shape;
+    p.dbias = dbias; p.shape = shape; p.X2 = X2; p.ldX2 = ldX2; p.col_off2 = col_off2; p.k_valid2 = k_valid2;
     return p;
 }
 

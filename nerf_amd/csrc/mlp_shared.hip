@@ -40,15 +40,16 @@ int launch_pack(const PackJobs& jobs, float* packed, hipStream_t stream) {
 
 // ---------------------------------------------------------------- wgrad ----
 // One workgroup (4 waves) owns one point slab of one part; wave w owns n-tiles
-// [w*NTW, (w+1)*NTW) and all KT k-tiles, i.e. NTW*KT accumulator tiles.
-// Operands come straight from the row-major activation / gradient rows: for one
-// MFMA k-step a wave reads two 128-byte row segments per tile.
-constexpr int WG_U = 4;  // k-steps (2 points each) per software-pipeline stage
+// [w*NTW, (w+1)*NTW) and all k-tiles (KT from X plus KT2 from X2), i.e.
+// NTW*(KT+KT2) accumulator tiles.  Operands come straight from the row-major
+// activation / gradient rows: for one MFMA k-step a wave reads two 128-byte row
+// segments per tile.  Loads run one stage (WG_U k-steps) ahead of the MFMAs.
+// U = k-steps (2 points each) per software-pipeline stage
 
-template <int NTW, int KT>
+template <int NTW, int KT, int KT2, int WG_U>
 struct WgradOperands {
     float a[WG_U][NTW];
-    float b[WG_U][KT];
+    float b[WG_U][KT + KT2];
     __device__ __forceinline__ void load(const WgradPart& pt, long long p, int n0, int i, int s) {
 #pragma unroll
         for (int u = 0; u < WG_U; ++u) {
@@ -57,12 +58,14 @@ struct WgradOperands {
             for (int nt = 0; nt < NTW; ++nt) a[u][nt] = pt.dY[row * pt.ldY + n0 + 32 * nt + i];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) b[u][kt] = pt.X[row * pt.ldX + 32 * kt + i];
+#pragma unroll
+            for (int kt = 0; kt < KT2; ++kt) b[u][KT + kt] = pt.X2[row * pt.ldX2 + 32 * kt + i];
         }
     }
 };
 
-template <int NTW, int KT>
-__device__ __forceinline__ void wgrad_accumulate(const WgradOperands<NTW, KT>& op, f32x16 (&acc)[NTW][KT],
+template <int NTW, int KT, int KT2, int WG_U>
+__device__ __forceinline__ void wgrad_accumulate(const WgradOperands<NTW, KT, KT2, WG_U>& op, f32x16 (&acc)[NTW][KT + KT2],
                                                  float (&bsum)[NTW]) {
 #pragma unroll
     for (int u = 0; u < WG_U; ++u)
@@ -70,44 +73,49 @@ __device__ __forceinline__ void wgrad_accumulate(const WgradOperands<NTW, KT>& o
         for (int nt = 0; nt < NTW; ++nt) {
             bsum[nt] += op.a[u][nt];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
+            for (int kt = 0; kt < KT + KT2; ++kt)
                 acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a[u][nt], op.b[u][kt], acc[nt][kt], 0, 0, 0);
         }
 }
 
-template <int NTW, int KT>
+template <int NTW, int KT, int KT2, int WG_U>
 __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane) {
     const int i = lane & 31, s = lane >> 5;
     const int n0 = wave * NTW * 32;
-    f32x16 acc[NTW][KT];
+    f32x16 acc[NTW][KT + KT2];
     float bsum[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         bsum[nt] = 0.0f;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = 0; kt < KT + KT2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][kt][r] = 0.0f;
     }
     constexpr int STEP = 2 * WG_U;  // points per stage; slabs are multiples of 2*STEP
-    WgradOperands<NTW, KT> opA, opB;
+    WgradOperands<NTW, KT, KT2, WG_U> opA, opB;
     opA.load(pt, p_begin, n0, i, s);
     for (long long p = p_begin; p < p_end; p += 2 * STEP) {
         opB.load(pt, p + STEP, n0, i, s);  // rows stay inside the slab: p + STEP < p_end
+        __builtin_amdgcn_sched_barrier(0);
         wgrad_accumulate(opA, acc, bsum);
+        __builtin_amdgcn_sched_barrier(0);
         if (p + 2 * STEP < p_end) opA.load(pt, p + 2 * STEP, n0, i, s);
+        __builtin_amdgcn_sched_barrier(0);
         wgrad_accumulate(opB, acc, bsum);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // dW[n0 + 32nt + rowmap(r,s)][col_off + 32kt + i]: per register two 128-byte row segments
+    // dW[n0 + 32nt + rowmap(r,s)][col + i]: per register two 128-byte row segments
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int k = 32 * kt + i;
-            if (k < pt.k_valid) {
+        for (int kt = 0; kt < KT + KT2; ++kt) {
+            const int k = (kt < KT ? 32 * kt : 32 * (kt - KT)) + i;
+            const int col = (kt < KT ? pt.col_off : pt.col_off2) + k;
+            if (k < (kt < KT ? pt.k_valid : pt.k_valid2)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    atomicAdd(pt.dW + (size_t)(n0 + 32 * nt + rowmap(r, s)) * pt.ldW + pt.col_off + k, acc[nt][kt][r]);
+                    atomicAdd(pt.dW + (size_t)(n0 + 32 * nt + rowmap(r, s)) * pt.ldW + col, acc[nt][kt][r]);
             }
         }
     if (pt.dbias) {
@@ -119,7 +127,7 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
     }
 }
 
-// shape ids: 0 = <2,8>, 1 = <2,2>, 2 = <1,8>, 3 = <1,1>, 4 = <2,1>
+// shape ids: 0 = <2,8,0>  1 = <2,8,2>  2 = <1,8,1>  3 = <2,2,0>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     int pi = 0;
 #pragma unroll 1
@@ -132,31 +140,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     if (t0 >= t1) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     switch (pt.shape) {
-        case 0: wgrad_part<2, 8>(pt, t0 * 32, t1 * 32, wave, lane); break;
-        case 1: wgrad_part<2, 2>(pt, t0 * 32, t1 * 32, wave, lane); break;
-        case 2: wgrad_part<1, 8>(pt, t0 * 32, t1 * 32, wave, lane); break;
-        case 3: wgrad_part<1, 1>(pt, t0 * 32, t1 * 32, wave, lane); break;
-        default: wgrad_part<2, 1>(pt, t0 * 32, t1 * 32, wave, lane); break;
+        case 0: wgrad_part<2, 8, 0, 4>(pt, t0 * 32, t1 * 32, wave, lane); break;
+        case 1: wgrad_part<2, 8, 2, 2>(pt, t0 * 32, t1 * 32, wave, lane); break;
+        case 2: wgrad_part<1, 8, 1, 4>(pt, t0 * 32, t1 * 32, wave, lane); break;
+        default: wgrad_part<2, 2, 0, 4>(pt, t0 * 32, t1 * 32, wave, lane); break;
     }
 }
 
-// Relative cost per point of each shape (accumulator tiles per wave).
-static const int kShapeCost[5] = {16, 4, 8, 1, 2};
+// MFMAs per k-step per wave of each shape (the cost model of the slab split).
+static const int kShapeCost[4] = {16, 20, 9, 4};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
-    // Split the parts into slabs of roughly equal cost, about two workgroups per CU in total.
+    // A workgroup takes a whole CU (512 registers per lane), so the grid is sized
+    // to exactly two equal-cost rounds of the 256 CUs: slabs proportional to cost.
     long long total_cost = 0;
     for (int i = 0; i < parts.n; ++i) total_cost += kShapeCost[parts.part[i].shape];
     const long long tiles = P32 / 32;
     const int target_blocks = 512;
-    int first = 0;
+    int used = 0;
     for (int i = 0; i < parts.n; ++i) {
-        long long s = (target_blocks * (long long)kShapeCost[parts.part[i].shape] + total_cost - 1) / total_cost;
+        long long s = target_blocks * (long long)kShapeCost[parts.part[i].shape] / total_cost;
         if (s < 1) s = 1;
         if (s > tiles) s = tiles;
         parts.part[i].slabs = (int)s;
+        used += (int)s;
+    }
+    // hand the remaining blocks to the parts with the most work per slab
+    while (used < target_blocks) {
+        int best = -1;
+        double best_load = 0.0;
+        for (int i = 0; i < parts.n; ++i) {
+            const double load = (double)kShapeCost[parts.part[i].shape] / parts.part[i].slabs;
+            if (parts.part[i].slabs < tiles && load > best_load) { best = i; best_load = load; }
+        }
+        if (best < 0) break;
+        ++parts.part[best].slabs;
+        ++used;
+    }
+    int first = 0;
+    for (int i = 0; i < parts.n; ++i) {
         parts.part[i].first_block = first;
-        first += (int)s;
+        first += parts.part[i].slabs;
     }
     parts.total_blocks = first;
     parts.P32 = P32;
