@@ -41,75 +41,133 @@ int launch_pack(const PackJobs& jobs, float* packed, hipStream_t stream) {
 // ---------------------------------------------------------------- wgrad ----
 // One workgroup (4 waves) owns one point slab of one part; wave w owns n-tiles
 // [w*NTW, (w+1)*NTW) and all k-tiles (KT from X plus KT2 from X2), i.e.
-// NTW*(KT+KT2) accumulator tiles.  Operands come straight from the row-major
-// activation / gradient rows: for one MFMA k-step a wave reads two 128-byte row
-// segments per tile.  Loads run one stage (WG_U k-steps) ahead of the MFMAs.
-// U = k-steps (2 points each) per software-pipeline stage
+// NTW*(KT+KT2) accumulator tiles (up to 320 registers).
+//
+// The slab is streamed through LDS in chunks of 32 points: the dY, X and X2 rows
+// of a chunk are copied global -> LDS by direct-to-LDS loads (16 B per lane, one
+// whole 1 KiB row segment per wave instruction), two chunk buffers deep, so the
+// loads of chunk c+1 are in flight during all 16 k-steps of chunk c (about 8 us
+// of cover for an HBM miss under load).  MFMA operands are then conflict-free
+// ds_read_b32 (32 consecutive floats per lane half), fetched one k-step ahead.
+constexpr int WG_CH = 32;                          // points per chunk
+constexpr int WG_LDS_FLOATS = 2 * WG_CH * (256 + 256);  // two buffers of the largest shape (128 KiB)
 
-template <int NTW, int KT, int KT2, int WG_U>
-struct WgradOperands {
-    float a[WG_U][NTW];
-    float b[WG_U][KT + KT2];
-    __device__ __forceinline__ void load(const WgradPart& pt, long long p, int n0, int i, int s) {
-#pragma unroll
-        for (int u = 0; u < WG_U; ++u) {
-            const long long row = p + 2 * u + s;
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) a[u][nt] = pt.dY[row * pt.ldY + n0 + 32 * nt + i];
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) b[u][kt] = pt.X[row * pt.ldX + 32 * kt + i];
-#pragma unroll
-            for (int kt = 0; kt < KT2; ++kt) b[u][KT + kt] = pt.X2[row * pt.ldX2 + 32 * kt + i];
-        }
-    }
+template <int NTW, int KT, int KT2>
+struct WgradShape {
+    static constexpr int N = NTW * 128, XW = KT * 32, X2W = KT2 * 32, KTT = KT + KT2;
+    static constexpr int DY_OFF = 0, X_OFF = WG_CH * N, X2_OFF = WG_CH * (N + XW);
+    static constexpr int CHUNK = WG_CH * (N + XW + X2W);   // floats per buffer
+    static_assert(CHUNK % 256 == 0, "a chunk must be a whole number of 1 KiB pieces");
+    static_assert(2 * CHUNK <= WG_LDS_FLOATS, "chunk buffers exceed the LDS allocation");
 };
 
-template <int NTW, int KT, int KT2, int WG_U>
-__device__ __forceinline__ void wgrad_accumulate(const WgradOperands<NTW, KT, KT2, WG_U>& op, f32x16 (&acc)[NTW][KT + KT2],
-                                                 float (&bsum)[NTW]) {
+// The source pointers of one part, copied out of the kernel-argument table once
+// (a direct-to-LDS load is an opaque memory write to the compiler: anything still
+// read through the table would be re-fetched, and waited for, after every piece).
+struct WgradSrc {
+    const float *dY, *X, *X2;
+    long long ldY, ldX, ldX2;
+};
+
+// Enqueue the direct-to-LDS copies of the chunk that starts at point p0.  Piece
+// `ins` is 1 KiB of the chunk buffer; the sub-block boundaries are multiples of
+// 1 KiB, so which source a piece reads is uniform over the wave.
+template <int NTW, int KT, int KT2>
+__device__ __forceinline__ void wgrad_stage(const WgradSrc& src, long long p0, float* buf, int wave, int lane) {
+    using S = WgradShape<NTW, KT, KT2>;
+    static_assert(S::X_OFF % 256 == 0 && S::X2_OFF % 256 == 0, "sub-blocks must start on a 1 KiB piece");
 #pragma unroll
-    for (int u = 0; u < WG_U; ++u)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            bsum[nt] += op.a[u][nt];
-#pragma unroll
-            for (int kt = 0; kt < KT + KT2; ++kt)
-                acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(op.a[u][nt], op.b[u][kt], acc[nt][kt], 0, 0, 0);
+    for (int piece = 0; piece < S::CHUNK / 256; piece += 4) {
+        const int ins = piece + wave;                 // this wave's piece (wave is uniform)
+        if (ins < S::CHUNK / 256) {
+            const float* g;
+            if (ins * 256 < S::X_OFF) {
+                const int off = ins * 256 + lane * 4;
+                g = src.dY + (p0 + off / S::N) * src.ldY + off % S::N;
+            } else if (KT2 == 0 || ins * 256 < S::X2_OFF) {
+                const int o = ins * 256 - S::X_OFF + lane * 4;
+                g = src.X + (p0 + o / S::XW) * src.ldX + o % S::XW;
+            } else {
+                const int o = ins * 256 - S::X2_OFF + lane * 4;
+                g = src.X2 + (p0 + o / (S::X2W ? S::X2W : 1)) * src.ldX2 + o % (S::X2W ? S::X2W : 1);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(buf + ins * 256), 16, 0, 0);
         }
+    }
 }
 
-template <int NTW, int KT, int KT2, int WG_U>
-__device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane) {
+template <int NTW, int KT, int KT2>
+__device__ __forceinline__ void wgrad_fetch(const float* buf, int u, int n0, int i, int s, float (&a)[NTW],
+                                            float (&b)[KT + KT2]) {
+    using S = WgradShape<NTW, KT, KT2>;
+    const int row = 2 * u + s;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) a[nt] = buf[S::DY_OFF + row * S::N + n0 + 32 * nt + i];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) b[kt] = buf[S::X_OFF + row * S::XW + 32 * kt + i];
+#pragma unroll
+    for (int kt = 0; kt < KT2; ++kt) b[KT + kt] = buf[S::X2_OFF + row * S::X2W + 32 * kt + i];
+}
+
+template <int NTW, int KTT>
+__device__ __forceinline__ void wgrad_mfma(const float (&a)[NTW], const float (&b)[KTT], f32x16 (&acc)[NTW][KTT],
+                                           float (&bsum)[NTW]) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        bsum[nt] += a[nt];
+#pragma unroll
+        for (int kt = 0; kt < KTT; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nt], b[kt], acc[nt][kt], 0, 0, 0);
+    }
+}
+
+template <int NTW, int KT, int KT2>
+__device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
+                                           float* lds) {
+    using S = WgradShape<NTW, KT, KT2>;
+    constexpr int KTT = KT + KT2;
     const int i = lane & 31, s = lane >> 5;
     const int n0 = wave * NTW * 32;
-    f32x16 acc[NTW][KT + KT2];
+    f32x16 acc[NTW][KTT];
     float bsum[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         bsum[nt] = 0.0f;
 #pragma unroll
-        for (int kt = 0; kt < KT + KT2; ++kt)
+        for (int kt = 0; kt < KTT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][kt][r] = 0.0f;
     }
-    constexpr int STEP = 2 * WG_U;  // points per stage; slabs are multiples of 2*STEP
-    WgradOperands<NTW, KT, KT2, WG_U> opA, opB;
-    opA.load(pt, p_begin, n0, i, s);
-    for (long long p = p_begin; p < p_end; p += 2 * STEP) {
-        opB.load(pt, p + STEP, n0, i, s);  // rows stay inside the slab: p + STEP < p_end
-        __builtin_amdgcn_sched_barrier(0);
-        wgrad_accumulate(opA, acc, bsum);
-        __builtin_amdgcn_sched_barrier(0);
-        if (p + 2 * STEP < p_end) opA.load(pt, p + 2 * STEP, n0, i, s);
-        __builtin_amdgcn_sched_barrier(0);
-        wgrad_accumulate(opB, acc, bsum);
-        __builtin_amdgcn_sched_barrier(0);
+    const WgradSrc src{pt.dY, pt.X, pt.X2, pt.ldY, pt.ldX, pt.ldX2};
+    wgrad_stage<NTW, KT, KT2>(src, p_begin, lds, wave, lane);
+    int cur = 0;
+#pragma unroll 1
+    for (long long p = p_begin; p < p_end; p += WG_CH) {
+        // Every wave's copies of this chunk have landed (the barrier's fence drains the
+        // wave's own direct-to-LDS loads first) and every wave is done with the other buffer.
+        __syncthreads();
+        if (p + WG_CH < p_end) wgrad_stage<NTW, KT, KT2>(src, p + WG_CH, lds + (cur ^ 1) * S::CHUNK, wave, lane);
+        const float* buf = lds + cur * S::CHUNK;
+        float a0[NTW], b0[KTT], a1[NTW], b1[KTT];
+        wgrad_fetch<NTW, KT, KT2>(buf, 0, n0, i, s, a0, b0);
+#pragma unroll
+        for (int u = 0; u < WG_CH / 2; u += 2) {
+            wgrad_fetch<NTW, KT, KT2>(buf, u + 1, n0, i, s, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            wgrad_mfma<NTW, KTT>(a0, b0, acc, bsum);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 2 < WG_CH / 2) wgrad_fetch<NTW, KT, KT2>(buf, u + 2, n0, i, s, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            wgrad_mfma<NTW, KTT>(a1, b1, acc, bsum);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
     }
     // dW[n0 + 32nt + rowmap(r,s)][col + i]: per register two 128-byte row segments
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int kt = 0; kt < KT + KT2; ++kt) {
+        for (int kt = 0; kt < KTT; ++kt) {
             const int k = (kt < KT ? 32 * kt : 32 * (kt - KT)) + i;
             const int col = (kt < KT ? pt.col_off : pt.col_off2) + k;
             if (k < (kt < KT ? pt.k_valid : pt.k_valid2)) {
@@ -127,8 +185,9 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
     }
 }
 
-// shape ids: 0 = <2,8,0>  1 = <2,8,2>  2 = <1,8,1>  3 = <2,2,0>
+// shape ids: 0 = <2,8,0>  1 = <1,8,1>  2 = <2,2,0>   (a 320-register <2,8,2> tile set does not allocate without spills)
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
+    __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
     int pi = 0;
 #pragma unroll 1
     while (pi + 1 < parts.n && (int)blockIdx.x >= parts.part[pi + 1].first_block) ++pi;
@@ -137,18 +196,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     // slab boundaries in units of 32 points
     const long long tiles = parts.P32 / 32;
     const long long t0 = tiles * slab / pt.slabs, t1 = tiles * (slab + 1) / pt.slabs;
-    if (t0 >= t1) return;
+    if (t0 >= t1) return;   // uniform for the whole workgroup
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     switch (pt.shape) {
-        case 0: wgrad_part<2, 8, 0, 4>(pt, t0 * 32, t1 * 32, wave, lane); break;
-        case 1: wgrad_part<2, 8, 2, 2>(pt, t0 * 32, t1 * 32, wave, lane); break;
-        case 2: wgrad_part<1, 8, 1, 4>(pt, t0 * 32, t1 * 32, wave, lane); break;
-        default: wgrad_part<2, 2, 0, 4>(pt, t0 * 32, t1 * 32, wave, lane); break;
+        case 0: wgrad_part<2, 8, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 1: wgrad_part<1, 8, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        default: wgrad_part<2, 2, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
     }
 }
 
 // MFMAs per k-step per wave of each shape (the cost model of the slab split).
-static const int kShapeCost[4] = {16, 20, 9, 4};
+static const int kShapeCost[3] = {16, 9, 4};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     // A workgroup takes a whole CU (512 registers per lane), so the grid is sized
