@@ -148,6 +148,37 @@ int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, int64_t P, co
                          const float* rgb, const float* sigma, float* ws, float* ws2,
                          int skip_h_first, float* const* grads, int phases, void* stream);
 
+/* Hash-grid NeRF, FastNGPNeRF.forward (src/models/FastNGPNeRF.py:79-110), fused:
+ * 16-level hash encoding (src/utils/hash_grid_encoder.py:42-107) + density MLP +
+ * colour MLP with the bias-free skip projection.  The kernel is specialised to
+ * the reference's defaults: 16 levels x 2 features, hidden width 64.
+ *
+ * `params`: host array of 9 device pointers
+ *   fc_density.0.weight (64,32), .bias (64), fc_density.2.weight (16,64), .bias (16),
+ *   fc_color.0.weight (64,42), .bias (64), fc_color.2.weight (3,64), .bias (3),
+ *   skip_proj.weight (64,15).
+ * tables / res / sizes: as nerf_hashgrid_fwd, exactly 16 levels.
+ */
+#define NERF_NGP_NPARAM 9
+size_t nerf_mlp_ngp_pack_floats(void);
+size_t nerf_mlp_ngp_ws_floats_per_point(void);
+size_t nerf_mlp_ngp_ws2_floats_per_point(void);
+int nerf_mlp_ngp_pack(const float* const* params, float* packed, void* stream);
+/* x [P,3]; dirs [ceil(P/dirs_div),3] un-normalised view directions (the kernel
+ * normalises them like the model does) or NULL for "no directions" (colour input
+ * zeros, src/models/FastNGPNeRF.py:100-103) -> rgb [P,3], sigma [P].
+ * ws: ceil32(P)*ws_floats_per_point floats, or NULL for inference. */
+int nerf_mlp_ngp_fwd(const float* x, const float* dirs, int dirs_div, int64_t P,
+                     const float* const* tables, const int* res, const int* sizes,
+                     const float* packed, float* rgb, float* sigma, float* ws, void* stream);
+/* Gradients of the 9 MLP parameters (`grads`, same order/shapes) and of the 16
+ * tables (`d_tables`), all ACCUMULATED with float atomics: zero them first.
+ * ws2: ceil32(P)*ws2_floats_per_point floats of scratch. */
+int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, int64_t P,
+                     const int* res, const int* sizes, const float* packed, const float* rgb,
+                     const float* sigma, float* ws, float* ws2, float* const* d_tables,
+                     float* const* grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,12 @@ SIGNATURES = {
     "nerf_mlp_vanilla_ws2_floats_per_point": (C.c_size_t, []),
     "nerf_mlp_vanilla_fwd": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P]),
     "nerf_mlp_vanilla_bwd": (_I, [_P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "nerf_mlp_ngp_pack_floats": (C.c_size_t, []),
+    "nerf_mlp_ngp_ws_floats_per_point": (C.c_size_t, []),
+    "nerf_mlp_ngp_ws2_floats_per_point": (C.c_size_t, []),
+    "nerf_mlp_ngp_pack": (_I, [_P, _P, _P]),
+    "nerf_mlp_ngp_fwd": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_mlp_ngp_bwd": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

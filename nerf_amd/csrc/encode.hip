@@ -3,6 +3,7 @@
 // scatter with float atomics).  Compiled with -ffp-contract=off so the
 // interpolation rounds like the reference's separate PyTorch ops.
 #include "common.h"
+#include "hashgrid.h"
 
 namespace nerf {
 
@@ -29,52 +30,6 @@ __global__ void encode_pe_kernel(const float* __restrict__ x, int64_t P, int D, 
 }
 
 // ----------------------------------------------------------- hash grid ----
-constexpr int HG_MAX_LEVELS = 32;
-
-struct HashLevels {
-    const float* table[HG_MAX_LEVELS];
-    int res[HG_MAX_LEVELS];
-    unsigned size[HG_MAX_LEVELS];
-};
-struct HashGradLevels {
-    float* table[HG_MAX_LEVELS];
-    int res[HG_MAX_LEVELS];
-    unsigned size[HG_MAX_LEVELS];
-};
-
-// Floor-modulo of a possibly negative cell coordinate (Python's % on int64,
-// src/utils/hash_grid_encoder.py:68-69).
-__device__ __forceinline__ unsigned wrap(long long v, int res) {
-    long long m = v % res;
-    if (m < 0) m += res;
-    return (unsigned)m;
-}
-
-// ((x*1 + y*2654435761 + z*805459861) & 0xFFFFFFFF) % size in the reference's
-// int64 arithmetic equals the 32-bit wrap-around sum (src/utils/hash_grid_encoder.py:39-40).
-__device__ __forceinline__ unsigned hash_row(unsigned cx, unsigned cy, unsigned cz, unsigned size) {
-    return (cx + cy * 2654435761u + cz * 805459861u) % size;
-}
-
-struct Cell {
-    unsigned lo[3], hi[3];
-    float w[3];
-};
-
-__device__ __forceinline__ Cell locate(const float* __restrict__ x, int64_t p, int res) {
-    Cell c;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float pos = x[p * 3 + k] * (float)res;   // :57
-        const float fl = floorf(pos);
-        const long long p0 = (long long)fl;           // :60
-        c.w[k] = pos - fl;                             // :64 (before wrapping)
-        c.lo[k] = wrap(p0, res);
-        c.hi[k] = wrap(p0 + 1, res);
-    }
-    return c;
-}
-
 // grid.y = level, one thread per point: a workgroup gathers from one table, so
 // the small tables stay in L2 and the large ones in the Infinity Cache.
 __global__ void hashgrid_fwd_kernel(const float* __restrict__ x, int64_t P, HashLevels lv, int levels,

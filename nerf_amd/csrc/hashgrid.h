@@ -1,0 +1,84 @@
+// Device helpers of the multiresolution hash grid shared by the stand-alone
+// encoder kernels and the fused hash-grid MLP (src/utils/hash_grid_encoder.py).
+#pragma once
+#include "common.h"
+
+namespace nerf {
+
+constexpr int HG_MAX_LEVELS = 32;
+
+struct HashLevels {
+    const float* table[HG_MAX_LEVELS];
+    int res[HG_MAX_LEVELS];
+    unsigned size[HG_MAX_LEVELS];
+};
+struct HashGradLevels {
+    float* table[HG_MAX_LEVELS];
+    int res[HG_MAX_LEVELS];
+    unsigned size[HG_MAX_LEVELS];
+};
+
+// Floor-modulo of a possibly negative cell coordinate (Python's % on int64,
+// src/utils/hash_grid_encoder.py:68-69).
+__device__ __forceinline__ unsigned wrap(long long v, int res) {
+    long long m = v % res;
+    if (m < 0) m += res;
+    return (unsigned)m;
+}
+
+// ((x*1 + y*2654435761 + z*805459861) & 0xFFFFFFFF) % size in the reference's
+// int64 arithmetic equals the 32-bit wrap-around sum (src/utils/hash_grid_encoder.py:39-40).
+__device__ __forceinline__ unsigned hash_row(unsigned cx, unsigned cy, unsigned cz, unsigned size) {
+    return (cx + cy * 2654435761u + cz * 805459861u) % size;
+}
+
+struct Cell {
+    unsigned lo[3], hi[3];
+    float w[3];
+};
+
+__device__ __forceinline__ Cell locate(const float* __restrict__ x, int64_t p, int res) {
+    Cell c;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float pos = x[p * 3 + k] * (float)res;   // :57
+        const float fl = floorf(pos);
+        const long long p0 = (long long)fl;           // :60
+        c.w[k] = pos - fl;                             // :64 (before wrapping)
+        c.lo[k] = wrap(p0, res);
+        c.hi[k] = wrap(p0 + 1, res);
+    }
+    return c;
+}
+
+
+// Trilinear interpolation of the 8 corner rows in the reference's order: along
+// x, then y, then z (src/utils/hash_grid_encoder.py:95-103), channel by channel.
+__device__ __forceinline__ float2 trilerp(const float2 (&f)[8], const float (&w)[3]) {
+    const float wx = w[0], wy = w[1], wz = w[2];
+    float r[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const float v000 = ch ? f[0].y : f[0].x, v001 = ch ? f[1].y : f[1].x, v010 = ch ? f[2].y : f[2].x,
+                    v011 = ch ? f[3].y : f[3].x, v100 = ch ? f[4].y : f[4].x, v101 = ch ? f[5].y : f[5].x,
+                    v110 = ch ? f[6].y : f[6].x, v111 = ch ? f[7].y : f[7].x;
+        const float x00 = v000 * (1.0f - wx) + v100 * wx;
+        const float x01 = v001 * (1.0f - wx) + v101 * wx;
+        const float x10 = v010 * (1.0f - wx) + v110 * wx;
+        const float x11 = v011 * (1.0f - wx) + v111 * wx;
+        const float y0 = x00 * (1.0f - wy) + x10 * wy;
+        const float y1 = x01 * (1.0f - wy) + x11 * wy;
+        r[ch] = y0 * (1.0f - wz) + y1 * wz;
+    }
+    return make_float2(r[0], r[1]);
+}
+
+__device__ __forceinline__ unsigned corner_row(const Cell& c, int corner, unsigned size) {  // corner bits = (x,y,z) offsets
+    return hash_row((corner & 4) ? c.hi[0] : c.lo[0], (corner & 2) ? c.hi[1] : c.lo[1], (corner & 1) ? c.hi[2] : c.lo[2], size);
+}
+__device__ __forceinline__ float corner_weight(const Cell& c, int corner) {
+    return (((corner & 4) ? c.w[0] : 1.0f - c.w[0]) * ((corner & 2) ? c.w[1] : 1.0f - c.w[1])) *
+           ((corner & 1) ? c.w[2] : 1.0f - c.w[2]);
+}
+
+}  // namespace nerf

@@ -24,12 +24,14 @@ __host__ __device__ __forceinline__ constexpr int rowmap(int r, int h) { return 
 template <int KT, int OT>
 __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16 (&in)[KT], f32x16 (&acc)[OT],
                                       int lane) {
-    static_assert(OT % 4 == 0, "OT must be a multiple of 4");
-    constexpr int V = OT / 4;
+    static_assert(OT % 4 == 0 || OT == 1 || OT == 2, "OT must be 1, 2 or a multiple of 4");
+    typedef float wvec __attribute__((ext_vector_type(OT >= 4 ? 4 : OT)));  // one load: 16, 8 or 4 bytes per lane
+    constexpr int W = OT >= 4 ? 4 : OT;
+    constexpr int V = OT / W;
     constexpr int S = KT * 16;       // k-steps; one step = OT MFMAs sharing one B register
     constexpr int D = S < 4 ? S : 4;  // steps of weight prefetch kept in flight (L2 latency >> one step)
-    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp) + lane * V;
-    float4 ring[D][V];
+    const wvec* __restrict__ w4 = reinterpret_cast<const wvec*>(wp) + lane * V;
+    wvec ring[D][V];
 #pragma unroll
     for (int s = 0; s < D; ++s)
 #pragma unroll
@@ -39,11 +41,9 @@ __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16
         float a[OT];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const float4 t = ring[s % D][v];
-            a[4 * v + 0] = t.x;
-            a[4 * v + 1] = t.y;
-            a[4 * v + 2] = t.z;
-            a[4 * v + 3] = t.w;
+            const wvec t = ring[s % D][v];
+#pragma unroll
+            for (int j = 0; j < W; ++j) a[W * v + j] = t[j];
         }
         if (s + D < S) {
 #pragma unroll
@@ -187,11 +187,15 @@ struct PackJob {
     const float* src;  // nn.Linear weight [N][ld] (row = output neuron)
     int dst;           // float offset in the packed buffer
     int ld, N;         // source leading dimension and row count
-    int mode;          // 0: forward pack, 1: backward (transposed) pack, 2: plain copy of `count` floats
+    int mode;          // 0: forward pack, 1: backward (transposed) pack, 2: plain copy of `count` floats, 3: zero fill
+    int hash_perm;     // hash-grid first layer: tile position rowmap(r,h) stands for feature 16h + r
     int KT, OT;        // tiles of the contraction / output dimension of the packed operand
     int seg_eff[2], seg_len[2], seg_src[2];  // forward: effective input k in [eff, eff+len) reads column src + (k-eff)
-    int col_begin, col_count;                 // backward: output m < col_count reads column col_begin + m
+    int col_begin, col_count;                 // backward: output m in [m_first, m_first+col_count) reads column col_begin + (m - m_first)
+    int m_first;
     int count;                                // copy mode
+    const float* add_src;                     // optional second weight added element-wise (same rows; forward: segment 0 only)
+    int add_ld;
 };
 constexpr int MAX_PACK_JOBS = 40;
 struct PackJobs {
@@ -211,8 +215,10 @@ struct WgradPart {
     float* dW;         // nn.Linear gradient [N][ldW]
     float* dbias;      // [N] or null
     int ldY, ldX, ldX2, ldW;
-    int col_off, col_off2;   // first gradient column written by the X / X2 tiles
-    int k_valid, k_valid2;   // columns >= k_valid within a block are padding and are not written
+    int col_off, col_off2;   // gradient column of input 0 of the X / X2 block (may be negative with k_first)
+    int k_first;             // X inputs below k_first are skipped (not written)
+    int k_valid, k_valid2;   // inputs >= k_valid within a block are padding and are not written
+    int n_valid;             // output rows >= n_valid are padding and are not written
     int shape;         // index into the (NTW, KT, KT2) instantiation list
     int slabs;         // point slabs this part is split into
     int first_block;   // prefix sum of slabs
@@ -257,12 +263,18 @@ inline PackJob pack_copy_job(const float* src, int dst, int count) {
     j.src = src; j.dst = dst; j.mode = 2; j.count = count;
     return j;
 }
+inline PackJob pack_zero_job(int dst, int count) {
+    PackJob j{};
+    j.dst = dst; j.mode = 3; j.count = count;
+    return j;
+}
 inline WgradPart wgrad_part_desc(const float* dY, int ldY, const float* X, int ldX, float* dW, int ldW, int col_off,
                                  int k_valid, float* dbias, int shape, const float* X2 = nullptr, int ldX2 = 0,
                                  int col_off2 = 0, int k_valid2 = 0) {
     WgradPart p{};
     p.dY = dY; p.ldY = ldY; p.X = X; p.ldX = ldX; p.dW = dW; p.ldW = ldW; p.col_off = col_off; p.k_valid = k_valid;
     p.dbias = dbias; p.shape = shape; p.X2 = X2; p.ldX2 = ldX2; p.col_off2 = col_off2; p.k_valid2 = k_valid2;
+    p.k_first = 0; p.n_valid = 1 << 30;
     return p;
 }
 

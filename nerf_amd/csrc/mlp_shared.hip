@@ -7,26 +7,40 @@ namespace nerf {
 // ------------------------------------------------------------- packing ----
 __global__ void pack_kernel(PackJobs jobs, float* __restrict__ packed) {
     const PackJob& jb = jobs.job[blockIdx.y];
-    const int total = jb.mode == 2 ? jb.count : jb.KT * 16 * 64 * jb.OT;
+    const int total = jb.mode >= 2 ? jb.count : jb.KT * 16 * 64 * jb.OT;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         float v = 0.0f;
         if (jb.mode == 2) {
             v = jb.src[idx];
+        } else if (jb.mode == 3) {
+            v = 0.0f;
         } else {
             const int ot = idx % jb.OT;
             const int lane = (idx / jb.OT) % 64;
             const int r = (idx / (jb.OT * 64)) % 16;
             const int kt = idx / (jb.OT * 64 * 16);
-            const int out_i = 32 * ot + (lane & 31);           // row of the packed operand (MFMA row i)
-            const int k = 32 * kt + rowmap(r, lane >> 5);      // contraction index
+            int out_i = 32 * ot + (lane & 31);                 // row of the packed operand (MFMA row i)
+            int k = 32 * kt + rowmap(r, lane >> 5);            // contraction index
+            if (jb.hash_perm) {   // tile position v = rowmap(r,h) <-> feature 16h + r
+                int& v32 = jb.mode == 0 ? k : out_i;
+                v32 = 16 * ((v32 >> 2) & 1) + (v32 & 3) + 4 * (v32 >> 3);
+            }
             if (jb.mode == 0) {  // forward: operand[n][k_eff] = W[n][col(k_eff)]
                 int col = -1;
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
                     if (k >= jb.seg_eff[s] && k < jb.seg_eff[s] + jb.seg_len[s]) col = jb.seg_src[s] + (k - jb.seg_eff[s]);
-                if (out_i < jb.N && col >= 0) v = jb.src[(size_t)out_i * jb.ld + col];
-            } else {             // backward: operand[m][n] = W[n][col_begin + m]
-                if (k < jb.N && out_i < jb.col_count) v = jb.src[(size_t)k * jb.ld + jb.col_begin + out_i];
+                if (out_i < jb.N && col >= 0) {
+                    v = jb.src[(size_t)out_i * jb.ld + col];
+                    if (jb.add_src && k >= jb.seg_eff[0] && k < jb.seg_eff[0] + jb.seg_len[0])
+                        v += jb.add_src[(size_t)out_i * jb.add_ld + col];
+                }
+            } else {             // backward: operand[m][n] = W[n][col_begin + (m - m_first)]
+                const int m = out_i - jb.m_first;
+                if (k < jb.N && m >= 0 && m < jb.col_count) {
+                    v = jb.src[(size_t)k * jb.ld + jb.col_begin + m];
+                    if (jb.add_src) v += jb.add_src[(size_t)k * jb.add_ld + jb.col_begin + m];
+                }
             }
         }
         packed[jb.dst + idx] = v;
@@ -52,9 +66,11 @@ int launch_pack(const PackJobs& jobs, float* packed, hipStream_t stream) {
 constexpr int WG_CH = 32;                          // points per chunk
 constexpr int WG_LDS_FLOATS = 2 * WG_CH * (256 + 256);  // two buffers of the largest shape (128 KiB)
 
-template <int NTW, int KT, int KT2>
+// NW = waves along the output dimension (N = NW*NTW*32 columns of dY); the other
+// 4/NW wave groups split the k-steps of every chunk between them.
+template <int NTW, int KT, int KT2, int NW = 4>
 struct WgradShape {
-    static constexpr int N = NTW * 128, XW = KT * 32, X2W = KT2 * 32, KTT = KT + KT2;
+    static constexpr int N = NW * NTW * 32, XW = KT * 32, X2W = KT2 * 32, KTT = KT + KT2, G = 4 / NW;
     static constexpr int DY_OFF = 0, X_OFF = WG_CH * N, X2_OFF = WG_CH * (N + XW);
     static constexpr int CHUNK = WG_CH * (N + XW + X2W);   // floats per buffer
     static_assert(CHUNK % 256 == 0, "a chunk must be a whole number of 1 KiB pieces");
@@ -72,9 +88,9 @@ struct WgradSrc {
 // Enqueue the direct-to-LDS copies of the chunk that starts at point p0.  Piece
 // `ins` is 1 KiB of the chunk buffer; the sub-block boundaries are multiples of
 // 1 KiB, so which source a piece reads is uniform over the wave.
-template <int NTW, int KT, int KT2>
+template <int NTW, int KT, int KT2, int NW>
 __device__ __forceinline__ void wgrad_stage(const WgradSrc& src, long long p0, float* buf, int wave, int lane) {
-    using S = WgradShape<NTW, KT, KT2>;
+    using S = WgradShape<NTW, KT, KT2, NW>;
     static_assert(S::X_OFF % 256 == 0 && S::X2_OFF % 256 == 0, "sub-blocks must start on a 1 KiB piece");
 #pragma unroll
     for (int piece = 0; piece < S::CHUNK / 256; piece += 4) {
@@ -97,10 +113,10 @@ __device__ __forceinline__ void wgrad_stage(const WgradSrc& src, long long p0, f
     }
 }
 
-template <int NTW, int KT, int KT2>
+template <int NTW, int KT, int KT2, int NW>
 __device__ __forceinline__ void wgrad_fetch(const float* buf, int u, int n0, int i, int s, float (&a)[NTW],
                                             float (&b)[KT + KT2]) {
-    using S = WgradShape<NTW, KT, KT2>;
+    using S = WgradShape<NTW, KT, KT2, NW>;
     const int row = 2 * u + s;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) a[nt] = buf[S::DY_OFF + row * S::N + n0 + 32 * nt + i];
@@ -121,13 +137,17 @@ __device__ __forceinline__ void wgrad_mfma(const float (&a)[NTW], const float (&
     }
 }
 
-template <int NTW, int KT, int KT2>
+template <int NTW, int KT, int KT2, int NW = 4>
 __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
                                            float* lds) {
-    using S = WgradShape<NTW, KT, KT2>;
+    using S = WgradShape<NTW, KT, KT2, NW>;
     constexpr int KTT = KT + KT2;
+    constexpr int G = S::G;                       // wave groups sharing the k-steps
+    constexpr int STEPS = WG_CH / 2 / G;          // k-steps per wave per chunk
+    static_assert(STEPS % 2 == 0, "the operand ping-pong needs an even step count");
     const int i = lane & 31, s = lane >> 5;
-    const int n0 = wave * NTW * 32;
+    const int n0 = (wave % NW) * NTW * 32;
+    const int g = wave / NW;
     f32x16 acc[NTW][KTT];
     float bsum[NTW];
 #pragma unroll
@@ -139,24 +159,24 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
             for (int r = 0; r < 16; ++r) acc[nt][kt][r] = 0.0f;
     }
     const WgradSrc src{pt.dY, pt.X, pt.X2, pt.ldY, pt.ldX, pt.ldX2};
-    wgrad_stage<NTW, KT, KT2>(src, p_begin, lds, wave, lane);
+    wgrad_stage<NTW, KT, KT2, NW>(src, p_begin, lds, wave, lane);
     int cur = 0;
 #pragma unroll 1
     for (long long p = p_begin; p < p_end; p += WG_CH) {
         // Every wave's copies of this chunk have landed (the barrier's fence drains the
         // wave's own direct-to-LDS loads first) and every wave is done with the other buffer.
         __syncthreads();
-        if (p + WG_CH < p_end) wgrad_stage<NTW, KT, KT2>(src, p + WG_CH, lds + (cur ^ 1) * S::CHUNK, wave, lane);
+        if (p + WG_CH < p_end) wgrad_stage<NTW, KT, KT2, NW>(src, p + WG_CH, lds + (cur ^ 1) * S::CHUNK, wave, lane);
         const float* buf = lds + cur * S::CHUNK;
         float a0[NTW], b0[KTT], a1[NTW], b1[KTT];
-        wgrad_fetch<NTW, KT, KT2>(buf, 0, n0, i, s, a0, b0);
+        wgrad_fetch<NTW, KT, KT2, NW>(buf, g, n0, i, s, a0, b0);
 #pragma unroll
-        for (int u = 0; u < WG_CH / 2; u += 2) {
-            wgrad_fetch<NTW, KT, KT2>(buf, u + 1, n0, i, s, a1, b1);
+        for (int j = 0; j < STEPS; j += 2) {   // this wave's k-steps are g, g+G, g+2G, ...
+            wgrad_fetch<NTW, KT, KT2, NW>(buf, g + G * (j + 1), n0, i, s, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
             wgrad_mfma<NTW, KTT>(a0, b0, acc, bsum);
             __builtin_amdgcn_sched_barrier(0);
-            if (u + 2 < WG_CH / 2) wgrad_fetch<NTW, KT, KT2>(buf, u + 2, n0, i, s, a0, b0);
+            if (j + 2 < STEPS) wgrad_fetch<NTW, KT, KT2, NW>(buf, g + G * (j + 2), n0, i, s, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
             wgrad_mfma<NTW, KTT>(a1, b1, acc, bsum);
             __builtin_amdgcn_sched_barrier(0);
@@ -170,22 +190,25 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
         for (int kt = 0; kt < KTT; ++kt) {
             const int k = (kt < KT ? 32 * kt : 32 * (kt - KT)) + i;
             const int col = (kt < KT ? pt.col_off : pt.col_off2) + k;
-            if (k < (kt < KT ? pt.k_valid : pt.k_valid2)) {
+            if (k < (kt < KT ? pt.k_valid : pt.k_valid2) && (kt >= KT || k >= pt.k_first)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    atomicAdd(pt.dW + (size_t)(n0 + 32 * nt + rowmap(r, s)) * pt.ldW + col, acc[nt][kt][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + 32 * nt + rowmap(r, s);
+                    if (n < pt.n_valid) atomicAdd(pt.dW + (size_t)n * pt.ldW + col, acc[nt][kt][r]);
+                }
             }
         }
     if (pt.dbias) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const float b = bsum[nt] + __shfl_xor(bsum[nt], 32, 64);
-            if (s == 0) atomicAdd(pt.dbias + n0 + 32 * nt + i, b);
+            if (s == 0 && n0 + 32 * nt + i < pt.n_valid) atomicAdd(pt.dbias + n0 + 32 * nt + i, b);
         }
     }
 }
 
-// shape ids: 0 = <2,8,0>  1 = <1,8,1>  2 = <2,2,0>   (a 320-register <2,8,2> tile set does not allocate without spills)
+// shape ids (NTW,KT,KT2,NW): 0 = <2,8,0,4>  1 = <1,8,1,4>  2 = <2,2,0,4>   (a 320-register <2,8,2> tile set does
+// not allocate without spills);  small layers of the hash-grid model: 3 = <1,1,0,2>  4 = <1,2,0,1>  5 = <1,1,1,2>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
     int pi = 0;
@@ -201,12 +224,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     switch (pt.shape) {
         case 0: wgrad_part<2, 8, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 1: wgrad_part<1, 8, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        default: wgrad_part<2, 2, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 2: wgrad_part<2, 2, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 3: wgrad_part<1, 1, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 4: wgrad_part<1, 2, 0, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        default: wgrad_part<1, 1, 1, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
     }
 }
 
 // MFMAs per k-step per wave of each shape (the cost model of the slab split).
-static const int kShapeCost[3] = {16, 9, 4};
+static const int kShapeCost[6] = {16, 9, 4, 4, 4, 4};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     // A workgroup takes a whole CU (512 registers per lane), so the grid is sized

@@ -286,3 +286,62 @@ class _VanillaMLP(torch.autograd.Function):
 
 def vanilla_mlp(x, dirs, params, skip_h_first: bool, dirs_div: int = 1):
     return _VanillaMLP.apply(x, dirs, int(dirs_div), bool(skip_h_first), *params)
+
+
+class _NgpMLP(torch.autograd.Function):
+    """Fused hash-grid NeRF: (x [P,3], dirs | None, 16 tables, 9 MLP parameters) ->
+    (rgb [P,3], sigma [P]).  MLP parameter order: fc_density.0.{weight,bias},
+    fc_density.2.{weight,bias}, fc_color.0.{weight,bias}, fc_color.2.{weight,bias},
+    skip_proj.weight.  Gradients go to the tables and the parameters."""
+
+    @staticmethod
+    def forward(ctx, x, dirs, dirs_div, res, *tensors):
+        tables, params = tensors[:16], tensors[16:]
+        assert len(tables) == 16 and len(params) == 9
+        L.need_gpu(x, dirs, *tensors)
+        lib = L.lib()
+        xc = L.f32c(x.detach())
+        dc = L.f32c(dirs.detach()) if dirs is not None else None
+        P = xc.shape[0]
+        assert xc.shape == (P, 3), "x must be [N,3]"
+        dev = xc.device
+        st = L.stream_of(xc)
+        tabs = [L.f32c(t.detach()) for t in tables]
+        ps = [L.f32c(p.detach()) for p in params]
+        sizes = [int(t.shape[0]) for t in tabs]
+        packed = torch.empty(lib.nerf_mlp_ngp_pack_floats(), device=dev)
+        L.check(lib.nerf_mlp_ngp_pack(L.ptr_array(ps), L.ptr(packed), st), "nerf_mlp_ngp_pack")
+        rgb = torch.empty(P, 3, device=dev)
+        sigma = torch.empty(P, device=dev)
+        train = any(ctx.needs_input_grad[4:])
+        ws = torch.empty(_ceil32(P) * lib.nerf_mlp_ngp_ws_floats_per_point(), device=dev) if train and P else None
+        L.check(lib.nerf_mlp_ngp_fwd(L.ptr(xc), L.ptr(dc), int(dirs_div), P, L.ptr_array(tabs), L.int_array(res),
+                                     L.int_array(sizes), L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), st),
+                "nerf_mlp_ngp_fwd")
+        if train:
+            ctx.save_for_backward(xc, packed, rgb, sigma, ws)
+            ctx.meta = (P, list(res), sizes, [t.shape for t in tensors])
+        ctx.set_materialize_grads(False)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        xc, packed, rgb, sigma, ws = ctx.saved_tensors
+        P, res, sizes, shapes = ctx.meta
+        lib = L.lib()
+        dev = rgb.device
+        grads = zero_grads_like(shapes, dev)
+        if P == 0:
+            return (None, None, None, None, *grads)
+        d_rgb = L.f32c(d_rgb) if d_rgb is not None else torch.zeros(P, 3, device=dev)
+        d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, device=dev)
+        ws2 = torch.empty(_ceil32(P) * lib.nerf_mlp_ngp_ws2_floats_per_point(), device=dev)
+        L.check(lib.nerf_mlp_ngp_bwd(L.ptr(xc), L.ptr(d_rgb), L.ptr(d_sigma), P, L.int_array(res), L.int_array(sizes),
+                                     L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(ws2),
+                                     L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.stream_of(rgb)),
+                "nerf_mlp_ngp_bwd")
+        return (None, None, None, None, *grads)
+
+
+def ngp_mlp(x, dirs, tables, params, res, dirs_div: int = 1):
+    return _NgpMLP.apply(x, dirs, int(dirs_div), list(res), *tables, *params)
