@@ -22,6 +22,9 @@ def _eval_model(model, pts, view_dirs, n_per_ray):
     if hasattr(model, "_params") and hasattr(model, "_skip_h_first"):
         # fused vanilla MLP: one direction row per ray serves all of its samples
         rgb, sigma = ops.vanilla_mlp(pts.reshape(-1, 3), view_dirs, model._params(), model._skip_h_first, dirs_div=N)
+    elif hasattr(model, "_tables"):
+        # fused hash-grid model: same one-row-per-ray trick
+        rgb, sigma = model(pts.reshape(-1, 3), view_dirs, dirs_div=N)
     else:
         dirs = view_dirs[:, None, :].expand(R, N, 3).reshape(-1, 3)
         rgb, sigma = model(pts.reshape(-1, 3), dirs)

@@ -1,0 +1,68 @@
+"""Ray-sharded data parallelism helpers, rehearsed with two gloo ranks on the CPU."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nerf_amd.dist import GradAverager, broadcast_parameters, gather_rows, shard_range
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                      # different init per rank on purpose
+        model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        broadcast_parameters(model, src=0)
+        params = list(model.parameters())
+        # every rank owns a slice of a global batch of "rays"
+        g = torch.Generator().manual_seed(5)
+        x_all, y_all = torch.randn(20, 7, generator=g), torch.randn(20, 3, generator=g)
+        b, e = shard_range(20, rank, world)
+        loss = torch.nn.functional.mse_loss(model(x_all[b:e]), y_all[b:e], reduction="sum") / 20
+        loss.backward()
+        params[-1].grad = None if rank == 1 else params[-1].grad   # a rank without a gradient contributes zeros
+        expect_last = None
+        avg = GradAverager(params)
+        avg.average()
+        # reference: the full-batch gradient on one process (sum over ranks, the averager divides by world)
+        ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        ref.load_state_dict(model.state_dict())
+        (torch.nn.functional.mse_loss(ref(x_all), y_all, reduction="sum") / 20).backward()
+        ok = True
+        for i, (p, q) in enumerate(zip(params[:-1], list(ref.parameters())[:-1])):
+            ok &= torch.allclose(p.grad * world, q.grad, atol=1e-6)
+        ok &= params[-1].grad is not None
+        rows = torch.full((e - b, 3), float(rank))
+        img = gather_rows(rows, [shard_range(20, r, world)[1] - shard_range(20, r, world)[0] for r in range(world)])
+        ok &= img.shape == (20, 3) and float(img[:b].sum()) == 0.0 * b and float(img[-1, 0]) == world - 1
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 8, 4096, 640000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_grad_average_and_gather_two_ranks():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
