@@ -187,8 +187,18 @@ def kernel_roofline(model, rays, dev):
     name = max(kernels, key=lambda k: kernels[k][0])
     t, flop = kernels[name]
     achieved = flop * P / t / 1e12
+    # HBM bytes per launch of that kernel from the committed PMC passes (measured
+    # offline with rocprofv3 --pmc: a counter run cannot be nested inside this one)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as fh:
+            tr = json.load(fh)
+        if tr.get("points_per_launch") == P and name in tr:
+            traffic = tr[name]["hbm_bytes"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
     return {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None, "points_per_launch": P,
+            "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic, "points_per_launch": P,
             "all_kernels_tflops": {k: v[1] * P / v[0] / 1e12 for k, v in kernels.items()},
             "all_kernels_ms": {k: v[0] * 1e3 for k, v in kernels.items()}}
 

@@ -1,6 +1,6 @@
 """Per-kernel, per-grid-size averages from a rocprofv3 --kernel-trace CSV.
 
-    python profiles/summarize_trace.py gpurun_out/<dir>/<pid>_kernel_trace.csv
+    python tools/summarize_trace.py gpurun_out/<dir>/<pid>_kernel_trace.csv
 
 The coarse (64-sample) and fine (192-sample) passes launch the same kernels at
 different grid sizes; the stats CSV averages them together, this splits them.
