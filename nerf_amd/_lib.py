@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerf_hip.so")
+LIB_PATH = os.environ.get("NERF_HIP_LIB", os.path.join(_HERE, "libnerf_hip.so"))  # override: A/B-testing a build
 
 _P = C.c_void_p
 _I = C.c_int

@@ -20,10 +20,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __host__ __device__ __forceinline__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// A 32-point x 256-wide tile staged in a wave-private LDS buffer (rows of 260
+// floats) that still has to be written to a row-major [P32][256] array.  The rows
+// are trickled out between the MFMA groups of the NEXT layer (one row every few
+// k-steps): every wave of the chip reaches its layer boundary at about the same
+// time, so storing the tile there is a 32 MB burst that stalls all of them on the
+// memory pipeline, while spread over the following 65k cycles it is free.
+constexpr int STAGE_LD = 256 + 4;
+struct PendingRows {
+    const float* lds;   // this wave's staging buffer
+    float* rows0;       // row 0 of the tile in global memory (leading dimension 256)
+};
+
 // acc[ot] += W_tile(ot, kt) * in[kt] for all tiles.  wp: packed [KT][16][64][OT].
-template <int KT, int OT>
+// DRAIN: also write the 32 pending rows of `pend` to global memory along the way.
+template <int KT, int OT, bool DRAIN = false>
 __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16 (&in)[KT], f32x16 (&acc)[OT],
-                                      int lane) {
+                                      int lane, PendingRows pend = PendingRows{nullptr, nullptr}) {
     static_assert(OT % 4 == 0 || OT == 1 || OT == 2, "OT must be 1, 2 or a multiple of 4");
     typedef float wvec __attribute__((ext_vector_type(OT >= 4 ? 4 : OT)));  // one load: 16, 8 or 4 bytes per lane
     constexpr int W = OT >= 4 ? 4 : OT;
@@ -32,6 +45,7 @@ __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16
     constexpr int D = S < 4 ? S : 4;  // steps of weight prefetch kept in flight (L2 latency >> one step)
     const wvec* __restrict__ w4 = reinterpret_cast<const wvec*>(wp) + lane * V;
     wvec ring[D][V];
+    float4 drain_buf = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < D; ++s)
 #pragma unroll
@@ -48,6 +62,15 @@ __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16
         if (s + D < S) {
 #pragma unroll
             for (int v = 0; v < V; ++v) ring[s % D][v] = w4[(size_t)((s + D) * 64) * V + v];
+        }
+        if constexpr (DRAIN) {
+            // row j is read from LDS at step PER*j and stored half a period later
+            constexpr int PER = S >= 64 ? S / 32 : 1;
+            static_assert(S >= 33, "too few k-steps to drain 32 rows");
+            if (s % PER == 0 && s / PER < 32)
+                drain_buf = *reinterpret_cast<const float4*>(pend.lds + (s / PER) * STAGE_LD + 4 * lane);
+            if (s >= (PER + 1) / 2 && (s - (PER + 1) / 2) % PER == 0 && (s - (PER + 1) / 2) / PER < 32)
+                *reinterpret_cast<float4*>(pend.rows0 + (size_t)((s - (PER + 1) / 2) / PER) * 256 + 4 * lane) = drain_buf;
         }
         // Pin the order "issue the prefetch, then this step's MFMAs": left alone the
         // scheduler sinks every load to just before its use and exposes its latency.
@@ -102,6 +125,58 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, const f32x16 
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(row + 32 * t + 8 * q + 4 * h) =
                 make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
+}
+
+// Coalesced form of store_row for a whole 32-point tile: the wave transposes its
+// registers through a private LDS buffer (32 rows of 32*NT + 4 floats; the pad
+// spreads the 8 rows of a ds_write_b128 group over all banks) and then writes
+// whole rows, 1 KiB contiguous per store instruction.  Stored straight from the
+// register layout a store instruction touches 32 different 128-byte lines, 32
+// bytes each, which costs the forward kernel ~14 % of its time.
+// rows0: row 0 of this tile in a row-major [P32][ld] array.
+constexpr int STORE_LDS_FLOATS_PER_WAVE = 32 * (256 + 4);
+template <int NT>
+__device__ __forceinline__ void drain_tile_rows(const float* __restrict__ lds_wave, float* __restrict__ rows0, int ld,
+                                                int lane);
+template <int NT>
+__device__ __forceinline__ void store_tile_rows(float* __restrict__ lds_wave, float* __restrict__ rows0, int ld,
+                                                const f32x16 (&a)[NT], int lane) {
+    constexpr int WIDTH = 32 * NT, LD = WIDTH + 4;
+    static_assert(256 % WIDTH == 0 && 32 * LD <= STORE_LDS_FLOATS_PER_WAVE, "tile does not fit the staging buffer");
+    const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(lds_wave + p * LD + 32 * t + 8 * q + 4 * h) =
+                make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
+    drain_tile_rows<NT>(lds_wave, rows0, ld, lane);
+}
+
+// First half of store_tile_rows only: park a 256-wide tile in the staging buffer
+// (layout of PendingRows); dense<..., DRAIN> or drain_tile_rows writes it out.
+__device__ __forceinline__ void stage_tile(float* __restrict__ lds_wave, const f32x16 (&a)[8], int lane) {
+    const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(lds_wave + p * STAGE_LD + 32 * t + 8 * q + 4 * h) =
+                make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
+}
+
+template <int NT>
+__device__ __forceinline__ void drain_tile_rows(const float* __restrict__ lds_wave, float* __restrict__ rows0, int ld,
+                                                int lane) {
+    constexpr int WIDTH = 32 * NT, LD = WIDTH + 4;
+    constexpr int ROWS_PER_INS = 256 / WIDTH;   // rows covered by one 64-lane float4 access
+    const int sub = (lane * 4) / WIDTH, col = (lane * 4) % WIDTH;
+#pragma unroll
+    for (int r0 = 0; r0 < 32; r0 += ROWS_PER_INS) {
+        const int row = r0 + sub;
+        const float4 v = *reinterpret_cast<const float4*>(lds_wave + row * LD + col);
+        *reinterpret_cast<float4*>(rows0 + (size_t)row * ld + col) = v;
+    }
 }
 
 // One bit per neuron: 1 where the (post-ReLU) activation is > 0.  Word t>>1, bit (t&1)*16 + r.

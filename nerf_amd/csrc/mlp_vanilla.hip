@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
                                                           long long P, const float* __restrict__ pk,
                                                           float* __restrict__ rgb, float* __restrict__ sigma,
                                                           float* __restrict__ ws, int dirs_div) {
+    __shared__ __attribute__((aligned(16))) float stage[4 * STORE_LDS_FLOATS_PER_WAVE];
+    float* lds_wave = stage + (threadIdx.x >> 6) * STORE_LDS_FLOATS_PER_WAVE;
     TileIdx ix;
     if (!tile_index(P, ix)) return;
     const int lane = ix.lane, h = ix.h;
@@ -83,43 +85,40 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
 
     f32x16 xe[2];
     pe_tiles<2>(xe, x0, x1, x2, 10, h);
-    if (SAVE) store_row<2>(ws + ix.P32 * vw::XE + ix.gp * 64, xe, h, true);
+    if (SAVE) store_tile_rows<2>(lds_wave, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64, xe, lane);
 
     f32x16 hc[8], acc[8];
-    // layer 0
-    fill_rows<8>(acc, pk + vp::S_BIAS, h);
-    dense<2, 8>(pk + vp::F_L0, xe, acc, lane);
-    relu_tiles<8>(acc);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) hc[t] = acc[t];
-    if (SAVE) {
-        store_row<8>(ws + ix.P32 * vw::H + ix.gp * 256, hc, h, true);
-        mask_out[0] = relu_bits<8>(hc);
-    }
+    // Training: the activations of layer l are parked in LDS at the layer boundary and
+    // written out row by row underneath the MFMAs of layer l+1 (see PendingRows).
+    auto rows_of = [&](int section) { return ws + ix.P32 * section + ix.tile * 32 * 256; };
     auto finish_layer = [&](int l) {
         relu_tiles<8>(acc);
 #pragma unroll
         for (int t = 0; t < 8; ++t) hc[t] = acc[t];
         if (SAVE) {
-            store_row<8>(ws + ix.P32 * (vw::H + 256 * l) + ix.gp * 256, hc, h, true);
+            stage_tile(lds_wave, hc, lane);
             mask_out[l * 64] = relu_bits<8>(hc);
         }
     };
+    // layer 0
+    fill_rows<8>(acc, pk + vp::S_BIAS, h);
+    dense<2, 8>(pk + vp::F_L0, xe, acc, lane);
+    finish_layer(0);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
         fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense<8, 8>(pk + vp::F_L1 + (l - 1) * vp::T88, hc, acc, lane);
+        dense<8, 8, SAVE>(pk + vp::F_L1 + (l - 1) * vp::T88, hc, acc, lane, PendingRows{lds_wave, rows_of(vw::H + 256 * (l - 1))});
         finish_layer(l);
     }
     // skip connection: the layer-4 input is [x_enc | h] (either column order, see the packing)
     fill_rows<8>(acc, pk + vp::S_BIAS + 256 * 4, h);
     dense<2, 8>(pk + vp::F_L4X, xe, acc, lane);
-    dense<8, 8>(pk + vp::F_L4H, hc, acc, lane);
+    dense<8, 8, SAVE>(pk + vp::F_L4H, hc, acc, lane, PendingRows{lds_wave, rows_of(vw::H + 256 * 3)});
     finish_layer(4);
 #pragma unroll 1
     for (int l = 5; l < 8; ++l) {
         fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense<8, 8>(pk + vp::F_L5 + (l - 5) * vp::T88, hc, acc, lane);
+        dense<8, 8, SAVE>(pk + vp::F_L5 + (l - 5) * vp::T88, hc, acc, lane, PendingRows{lds_wave, rows_of(vw::H + 256 * (l - 1))});
         finish_layer(l);
     }
     // density head: softplus(w.h + b)   (NeRF.py:90)
@@ -127,20 +126,22 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(sp);
     // feature layer (no activation)      (NeRF.py:95)
     fill_rows<8>(acc, pk + vp::S_BF, h);
-    dense<8, 8>(pk + vp::F_FEAT, hc, acc, lane);
-    if (SAVE) store_row<8>(ws + ix.P32 * vw::FEAT + ix.gp * 256, acc, h, true);
+    dense<8, 8, SAVE>(pk + vp::F_FEAT, hc, acc, lane, PendingRows{lds_wave, rows_of(vw::H + 256 * 7)});
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
     const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
     pe_tiles<1>(de, dirs[3 * dr], dirs[3 * dr + 1], dirs[3 * dr + 2], 4, h);
-    if (SAVE) store_row<1>(ws + ix.P32 * vw::DE + ix.gp * 32, de, h, true);
+    if (SAVE) {
+        store_tile_rows<1>(lds_wave, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32, de, lane);
+        stage_tile(lds_wave, acc, lane);   // the feature rows leave underneath the colour layer
+    }
     f32x16 hr[4];
     fill_rows<4>(hr, pk + vp::S_B1, h);
-    dense<8, 4>(pk + vp::F_RGB0F, acc, hr, lane);
+    dense<8, 4, SAVE>(pk + vp::F_RGB0F, acc, hr, lane, PendingRows{lds_wave, rows_of(vw::FEAT)});
     dense<1, 4>(pk + vp::F_RGB0D, de, hr, lane);
     relu_tiles<4>(hr);
     if (SAVE) {
-        store_row<4>(ws + ix.P32 * vw::HR + ix.gp * 128, hr, h, true);
+        store_tile_rows<4>(lds_wave, ws + ix.P32 * vw::HR + ix.tile * 32 * 128, 128, hr, lane);
         mask_out[8 * 64] = relu_bits<4>(hr);
     }
 #pragma unroll
@@ -157,6 +158,8 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
                                                                const float* __restrict__ rgb,
                                                                const float* __restrict__ sigma,
                                                                const float* __restrict__ ws, float* __restrict__ ws2) {
+    __shared__ __attribute__((aligned(16))) float stage[4 * STORE_LDS_FLOATS_PER_WAVE];
+    float* lds_wave = stage + (threadIdx.x >> 6) * STORE_LDS_FLOATS_PER_WAVE;
     TileIdx ix;
     if (!tile_index(P, ix)) return;
     const int lane = ix.lane, h = ix.h;
@@ -191,14 +194,16 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
             dyr[t][4 * q + 3] = s.w;
         }
     apply_bits<4>(dyr, mask_in[8 * 64]);
-    store_row<4>(ws2 + ix.P32 * vw::DYR + ix.gp * 128, dyr, h, true);
+    store_tile_rows<4>(lds_wave, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128, dyr, lane);
 
+    // Each 256-wide gradient tile is parked in LDS and written out underneath the next layer's MFMAs.
+    auto rows_of = [&](int section) { return ws2 + ix.P32 * section + ix.tile * 32 * 256; };
     f32x16 a[8], b[8];
     zero_tiles<8>(a);
     dense<4, 8>(pk + vp::B_RGB0, dyr, a, lane);   // d feat
-    store_row<8>(ws2 + ix.P32 * vw::DFEAT + ix.gp * 256, a, h, true);
+    stage_tile(lds_wave, a, lane);
     zero_tiles<8>(b);
-    dense<8, 8>(pk + vp::B_FEAT, a, b, lane);     // d h7 through the feature layer ...
+    dense<8, 8, true>(pk + vp::B_FEAT, a, b, lane, PendingRows{lds_wave, rows_of(vw::DFEAT)});   // d h7 through the feature layer ...
 #pragma unroll
     for (int t = 0; t < 8; ++t)                    // ... plus the density head
 #pragma unroll
@@ -210,16 +215,17 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
             b[t][4 * q + 3] = fmaf(w.w, dps, b[t][4 * q + 3]);
         }
     apply_bits<8>(b, mask_in[7 * 64]);
-    store_row<8>(ws2 + ix.P32 * (vw::DY + 7 * 256) + ix.gp * 256, b, h, true);
+    stage_tile(lds_wave, b, lane);
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                 // d h_{l-1} = W_l^T d y_l (h columns only at l = 4)
         zero_tiles<8>(a);
-        dense<8, 8>(pk + vp::B_L7 + (7 - l) * vp::T88, b, a, lane);
+        dense<8, 8, true>(pk + vp::B_L7 + (7 - l) * vp::T88, b, a, lane, PendingRows{lds_wave, rows_of(vw::DY + l * 256)});
         apply_bits<8>(a, mask_in[(l - 1) * 64]);
-        store_row<8>(ws2 + ix.P32 * (vw::DY + (l - 1) * 256) + ix.gp * 256, a, h, true);
+        stage_tile(lds_wave, a, lane);
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[t] = a[t];
     }
+    drain_tile_rows<8>(lds_wave, rows_of(vw::DY), 256, lane);
 }
 
 }  // namespace nerf
