@@ -77,63 +77,102 @@ struct WgradShape {
     static_assert(2 * CHUNK <= WG_LDS_FLOATS, "chunk buffers exceed the LDS allocation");
 };
 
-// The source pointers of one part, copied out of the kernel-argument table once
-// (a direct-to-LDS load is an opaque memory write to the compiler: anything still
-// read through the table would be re-fetched, and waited for, after every piece).
+// Per-lane source pointers of one part for the direct-to-LDS copies, built once from
+// the kernel-argument table (a direct-to-LDS load is an opaque memory write to the
+// compiler: anything still read through the table would be re-fetched, and waited
+// for, after every piece).
+//
+// A chunk buffer is copied in pieces of 1 KiB (one wave instruction, 16 B per lane);
+// the four waves take pieces 4q..4q+3 together.  Every sub-block (dY, X, X2) is a
+// whole number of 4 KiB and every row length divides 1024 floats, so the source of
+// piece group q is known at compile time and a lane's (row, column) within the group
+// never changes: pointer = lane base + (p0 + q * rows per group) * row stride.
+template <int NTW, int KT, int KT2, int NW>
 struct WgradSrc {
+    using S = WgradShape<NTW, KT, KT2, NW>;
+    static constexpr int X2W = S::X2W ? S::X2W : 32;
+    static_assert(1024 % S::N == 0 && 1024 % S::XW == 0 && 1024 % X2W == 0, "row lengths must divide a piece group");
+    static_assert(S::X_OFF % 1024 == 0 && S::X2_OFF % 1024 == 0 && S::CHUNK % 1024 == 0, "sub-blocks must be whole piece groups");
+    static constexpr int GROUPS = S::CHUNK / 1024;   // pieces per wave per chunk
     const float *dY, *X, *X2;
     long long ldY, ldX, ldX2;
-};
+    int wave;
 
-// Enqueue the direct-to-LDS copies of the chunk that starts at point p0.  Piece
-// `ins` is 1 KiB of the chunk buffer; the sub-block boundaries are multiples of
-// 1 KiB, so which source a piece reads is uniform over the wave.
-template <int NTW, int KT, int KT2, int NW>
-__device__ __forceinline__ void wgrad_stage(const WgradSrc& src, long long p0, float* buf, int wave, int lane) {
-    using S = WgradShape<NTW, KT, KT2, NW>;
-    static_assert(S::X_OFF % 256 == 0 && S::X2_OFF % 256 == 0, "sub-blocks must start on a 1 KiB piece");
+    __device__ __forceinline__ WgradSrc(const WgradPart& pt, int wave_, int lane) : wave(wave_) {
+        const int off = 256 * wave_ + 4 * lane;       // float offset of this lane within a piece group
+        ldY = pt.ldY; ldX = pt.ldX; ldX2 = pt.ldX2;
+        dY = pt.dY + (off / S::N) * ldY + off % S::N;
+        X = pt.X + (off / S::XW) * ldX + off % S::XW;
+        X2 = KT2 ? pt.X2 + (off / X2W) * ldX2 + off % X2W : nullptr;
+    }
+
+    // Enqueue piece groups [Q0, Q1) of the chunk that starts at point p0 into buf.
+    template <int Q0, int Q1>
+    __device__ __forceinline__ void stage(long long p0, float* buf) const {
 #pragma unroll
-    for (int piece = 0; piece < S::CHUNK / 256; piece += 4) {
-        const int ins = piece + wave;                 // this wave's piece (wave is uniform)
-        if (ins < S::CHUNK / 256) {
+        for (int q = Q0; q < Q1; ++q) {
             const float* g;
-            if (ins * 256 < S::X_OFF) {
-                const int off = ins * 256 + lane * 4;
-                g = src.dY + (p0 + off / S::N) * src.ldY + off % S::N;
-            } else if (KT2 == 0 || ins * 256 < S::X2_OFF) {
-                const int o = ins * 256 - S::X_OFF + lane * 4;
-                g = src.X + (p0 + o / S::XW) * src.ldX + o % S::XW;
+            if (q * 1024 < S::X_OFF) {
+                g = dY + (p0 + q * (1024 / S::N)) * ldY;
+            } else if (KT2 == 0 || q * 1024 < S::X2_OFF) {
+                g = X + (p0 + (q - S::X_OFF / 1024) * (1024 / S::XW)) * ldX;
             } else {
-                const int o = ins * 256 - S::X2_OFF + lane * 4;
-                g = src.X2 + (p0 + o / (S::X2W ? S::X2W : 1)) * src.ldX2 + o % (S::X2W ? S::X2W : 1);
+                g = X2 + (p0 + (q - S::X2_OFF / 1024) * (1024 / X2W)) * ldX2;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(buf + ins * 256), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(buf + q * 1024 + wave * 256), 16, 0, 0);
         }
     }
+};
+
+// LDS reads of the MFMA operands are issued as asm: the compiler would order them
+// (and the waits for them) by its own cost model, and it makes every LDS read it
+// knows of wait for the direct-to-LDS copies in flight.  The waits are explicit:
+// lds_wait() before the first use of what lds_read() requested.
+template <int OFF_BYTES>
+__device__ __forceinline__ float lds_read(unsigned addr) {
+    float r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF_BYTES));
+    return r;
+}
+template <int NA, int NB>
+__device__ __forceinline__ void lds_wait(float (&a)[NA], float (&b)[NB]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the operands pass through an empty asm so that no use of them can move above the wait
+#pragma unroll
+    for (int k = 0; k < NA; ++k) asm volatile("" : "+v"(a[k]));
+#pragma unroll
+    for (int k = 0; k < NB; ++k) asm volatile("" : "+v"(b[k]));
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
 }
 
-template <int NTW, int KT, int KT2, int NW>
-__device__ __forceinline__ void wgrad_fetch(const float* buf, int u, int n0, int i, int s, float (&a)[NTW],
-                                            float (&b)[KT + KT2]) {
+// LDS byte addresses of this lane's operand rows at k-step 0 of a chunk buffer.
+struct WgradRows {
+    unsigned dy, x, x2;
+};
+
+// Request the MFMA operands of the wave's k-step number J (points 2u and 2u+1 of
+// the chunk, u = g + G*J; g is folded into the row addresses).
+template <int NTW, int KT, int KT2, int NW, int J>
+__device__ __forceinline__ void wgrad_fetch(const WgradRows& rows, float (&a)[NTW], float (&b)[KT + KT2]) {
     using S = WgradShape<NTW, KT, KT2, NW>;
-    const int row = 2 * u + s;
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) a[nt] = buf[S::DY_OFF + row * S::N + n0 + 32 * nt + i];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) b[kt] = buf[S::X_OFF + row * S::XW + 32 * kt + i];
-#pragma unroll
-    for (int kt = 0; kt < KT2; ++kt) b[KT + kt] = buf[S::X2_OFF + row * S::X2W + 32 * kt + i];
+    constexpr int U = S::G * J;
+    static_for<0, NTW>([&](auto nt) { a[nt] = lds_read<(2 * U * S::N + 32 * decltype(nt)::value) * 4>(rows.dy); });
+    static_for<0, KT>([&](auto kt) { b[kt] = lds_read<(2 * U * S::XW + 32 * decltype(kt)::value) * 4>(rows.x); });
+    static_for<0, KT2>([&](auto kt) { b[KT + kt] = lds_read<(2 * U * S::X2W + 32 * decltype(kt)::value) * 4>(rows.x2); });
 }
 
-template <int NTW, int KTT>
-__device__ __forceinline__ void wgrad_mfma(const float (&a)[NTW], const float (&b)[KTT], f32x16 (&acc)[NTW][KTT],
-                                           float (&bsum)[NTW]) {
+// MFMAs [M0, M1) of a k-step, numbered nt * KTT + kt.  Each result passes through an
+// empty asm: an MFMA is a pure operation to the compiler, which would otherwise sink
+// the MFMAs of a whole chunk below all of its LDS reads.
+template <int NTW, int KTT, int M0, int M1>
+__device__ __forceinline__ void wgrad_mfma(const float (&a)[NTW], const float (&b)[KTT], f32x16 (&acc)[NTW][KTT]) {
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        bsum[nt] += a[nt];
-#pragma unroll
-        for (int kt = 0; kt < KTT; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nt], b[kt], acc[nt][kt], 0, 0, 0);
+    for (int m = M0; m < M1; ++m) {
+        acc[m / KTT][m % KTT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m / KTT], b[m % KTT], acc[m / KTT][m % KTT], 0, 0, 0);
+        asm volatile("" : "+a"(acc[m / KTT][m % KTT]));
     }
 }
 
@@ -144,6 +183,7 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
     constexpr int KTT = KT + KT2;
     constexpr int G = S::G;                       // wave groups sharing the k-steps
     constexpr int STEPS = WG_CH / 2 / G;          // k-steps per wave per chunk
+    constexpr int M = NTW * KTT;                  // MFMAs per k-step
     static_assert(STEPS % 2 == 0, "the operand ping-pong needs an even step count");
     const int i = lane & 31, s = lane >> 5;
     const int n0 = (wave % NW) * NTW * 32;
@@ -158,29 +198,56 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][kt][r] = 0.0f;
     }
-    const WgradSrc src{pt.dY, pt.X, pt.X2, pt.ldY, pt.ldX, pt.ldX2};
-    wgrad_stage<NTW, KT, KT2, NW>(src, p_begin, lds, wave, lane);
+    const WgradSrc<NTW, KT, KT2, NW> src(pt, wave, lane);
+    constexpr int PW = WgradSrc<NTW, KT, KT2, NW>::GROUPS;
+    src.template stage<0, PW>(p_begin, lds);
     int cur = 0;
 #pragma unroll 1
     for (long long p = p_begin; p < p_end; p += WG_CH) {
         // Every wave's copies of this chunk have landed (the barrier's fence drains the
         // wave's own direct-to-LDS loads first) and every wave is done with the other buffer.
         __syncthreads();
-        if (p + WG_CH < p_end) wgrad_stage<NTW, KT, KT2, NW>(src, p + WG_CH, lds + (cur ^ 1) * S::CHUNK, wave, lane);
+        const bool more = p + WG_CH < p_end;
         const float* buf = lds + cur * S::CHUNK;
+        float* nxt = lds + (cur ^ 1) * S::CHUNK;
+        const WgradRows rows{lds_addr(buf + S::DY_OFF + (2 * g + s) * S::N + n0 + i),
+                             lds_addr(buf + S::X_OFF + (2 * g + s) * S::XW + i),
+                             lds_addr(buf + S::X2_OFF + (2 * g + s) * S::X2W + i)};
         float a0[NTW], b0[KTT], a1[NTW], b1[KTT];
-        wgrad_fetch<NTW, KT, KT2, NW>(buf, g, n0, i, s, a0, b0);
+        wgrad_fetch<NTW, KT, KT2, NW, 0>(rows, a0, b0);
+        // Schedule of a k-step: wait for its operands (requested a whole step earlier),
+        // its first MFMA, then the LDS reads of the next step and a share of the next
+        // chunk's copies, then the other MFMAs.  The copies all go out in the first
+        // STAGE_STEPS steps, so that the last of them has the remaining steps to land
+        // before the barrier waits for it.
+        constexpr int STAGE_STEPS = STEPS * 3 / 8 > 0 ? STEPS * 3 / 8 : 1;
+        constexpr int PPS = (PW + STAGE_STEPS - 1) / STAGE_STEPS;
+        constexpr auto q_of = [](int step) { return step * PPS < PW ? step * PPS : PW; };
+        static_for<0, STEPS / 2>([&](auto jj) {   // this wave's k-steps are g, g+G, g+2G, ...
+            constexpr int j = 2 * decltype(jj)::value;
+            lds_wait(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            wgrad_mfma<NTW, KTT, 0, 1>(a0, b0, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            wgrad_fetch<NTW, KT, KT2, NW, j + 1>(rows, a1, b1);
+            if (more) src.template stage<q_of(j), q_of(j + 1)>(p + WG_CH, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            wgrad_mfma<NTW, KTT, 1, M>(a0, b0, acc);
 #pragma unroll
-        for (int j = 0; j < STEPS; j += 2) {   // this wave's k-steps are g, g+G, g+2G, ...
-            wgrad_fetch<NTW, KT, KT2, NW>(buf, g + G * (j + 1), n0, i, s, a1, b1);
+            for (int nt = 0; nt < NTW; ++nt) bsum[nt] += a0[nt];
             __builtin_amdgcn_sched_barrier(0);
-            wgrad_mfma<NTW, KTT>(a0, b0, acc, bsum);
+            lds_wait(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
-            if (j + 2 < STEPS) wgrad_fetch<NTW, KT, KT2, NW>(buf, g + G * (j + 2), n0, i, s, a0, b0);
+            wgrad_mfma<NTW, KTT, 0, 1>(a1, b1, acc);
             __builtin_amdgcn_sched_barrier(0);
-            wgrad_mfma<NTW, KTT>(a1, b1, acc, bsum);
+            if constexpr (j + 2 < STEPS) wgrad_fetch<NTW, KT, KT2, NW, j + 2>(rows, a0, b0);
+            if (more) src.template stage<q_of(j + 1), q_of(j + 2)>(p + WG_CH, nxt);
             __builtin_amdgcn_sched_barrier(0);
-        }
+            wgrad_mfma<NTW, KTT, 1, M>(a1, b1, acc);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) bsum[nt] += a1[nt];
+            __builtin_amdgcn_sched_barrier(0);
+        });
         cur ^= 1;
     }
     // dW[n0 + 32nt + rowmap(r,s)][col + i]: per register two 128-byte row segments
@@ -209,8 +276,18 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
 
 // shape ids (NTW,KT,KT2,NW): 0 = <2,8,0,4>  1 = <1,8,1,4>  2 = <2,2,0,4>   (a 320-register <2,8,2> tile set does
 // not allocate without spills);  small layers of the hash-grid model: 3 = <1,1,0,2>  4 = <1,2,0,1>  5 = <1,1,1,2>
+#ifdef NERF_WG_TIMING
+__device__ unsigned long long g_wg_time[4096];
+extern "C" int nerf_debug_wg_times(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_time), sizeof(g_wg_time));
+}
+#endif
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
+#ifdef NERF_WG_TIMING
+    const unsigned long long t_start = wall_clock64();
+    const unsigned long long c_start = clock64();
+#endif
     int pi = 0;
 #pragma unroll 1
     while (pi + 1 < parts.n && (int)blockIdx.x >= parts.part[pi + 1].first_block) ++pi;
@@ -229,10 +306,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
         case 4: wgrad_part<1, 2, 0, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         default: wgrad_part<1, 1, 1, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
     }
+#ifdef NERF_WG_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_wg_time[4 * blockIdx.x] = t_start;
+        g_wg_time[4 * blockIdx.x + 1] = wall_clock64();
+        g_wg_time[4 * blockIdx.x + 2] = c_start;
+        g_wg_time[4 * blockIdx.x + 3] = clock64();
+    }
+#endif
 }
 
-// MFMAs per k-step per wave of each shape (the cost model of the slab split).
-static const int kShapeCost[6] = {16, 9, 4, 4, 4, 4};
+// Relative time per point of a workgroup of each shape (measured for the first three; the
+// narrow shapes run below their MFMA count): the cost model of the slab split.
+static const int kShapeCost[6] = {32, 19, 10, 8, 8, 8};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     // A workgroup takes a whole CU (512 registers per lane), so the grid is sized
@@ -273,38 +359,75 @@ int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
 }
 
 // -------------------------------------------------------- small heads ----
-// Thread k of a block accumulates dW[c][k] over the block's point range.
+// dW[c][k] += sum_p dY[p][c0+c] X[p][k] for heads of at most 4 outputs: bandwidth
+// work (X is read once).  A block owns a point range; K/4 threads cover one row
+// of X with 16-byte loads and the 1024/K row groups of the block stride through
+// the range, several loads in flight each; the row groups are then summed in LDS.
+template <int K>
 __global__ __launch_bounds__(256) void skinny_wgrad_kernel(SkinnyPart pt, long long P32) {
-    const int k = threadIdx.x;
+    constexpr int L = K / 4, R = 256 / L;     // threads per row, rows per pass
+    __shared__ float red[R][4][K];
+    const int c4 = threadIdx.x % L, rs = threadIdx.x / L;
     const long long per = (P32 + gridDim.x - 1) / gridDim.x;
     const long long p0 = per * blockIdx.x, p1 = min(P32, p0 + per);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long p = p0; p < p1; ++p) {
-        const float x = k < pt.K ? pt.X[p * pt.ldX + k] : 0.0f;
+    float4 acc[4];
+    float bs[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { acc[c] = make_float4(0.f, 0.f, 0.f, 0.f); bs[c] = 0.f; }
+    const float* xp = pt.X + 4 * c4;
+#pragma unroll 4
+    for (long long p = p0 + rs; p < p1; p += R) {
+        const float4 x = *reinterpret_cast<const float4*>(xp + p * pt.ldX);
+        const float4 g4 = *reinterpret_cast<const float4*>(pt.dY + p * 4);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c < pt.C) {
-                const float g = pt.dY[p * pt.ldY + pt.c0 + c];
-                acc[c] = fmaf(g, x, acc[c]);
-                bs[c] += g;
+                const int ch = pt.c0 + c;
+                const float gc = ch == 0 ? g4.x : ch == 1 ? g4.y : ch == 2 ? g4.z : g4.w;
+                acc[c].x = fmaf(gc, x.x, acc[c].x);
+                acc[c].y = fmaf(gc, x.y, acc[c].y);
+                acc[c].z = fmaf(gc, x.z, acc[c].z);
+                acc[c].w = fmaf(gc, x.w, acc[c].w);
+                bs[c] += gc;
             }
         }
     }
-    if (k < pt.K) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < pt.C) atomicAdd(pt.dW + c * pt.K + k, acc[c]);
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(&red[rs][c][4 * c4]) = acc[c];
+    __syncthreads();
+    for (int e = threadIdx.x; e < pt.C * K; e += 256) {
+        const int c = e / K, k = e % K;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) sum += red[r][c][k];
+        atomicAdd(pt.dW + c * K + k, sum);
     }
-    if (k == 0 && pt.dbias) {
+    if (pt.dbias) {
+        __syncthreads();
+        if (c4 == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < pt.C) atomicAdd(pt.dbias + c, bs[c]);
+            for (int c = 0; c < 4; ++c) red[rs][c][0] = bs[c];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < pt.C) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) sum += red[r][threadIdx.x][0];
+            atomicAdd(pt.dbias + threadIdx.x, sum);
+        }
     }
 }
 
 int launch_skinny(const SkinnyPart& pt, long long P32, hipStream_t stream) {
-    const int blocks = (int)((P32 / 32 < 1024) ? (P32 / 32 > 0 ? P32 / 32 : 1) : 1024);
-    hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(blocks), dim3(256), 0, stream, pt, P32);
+    NERF_REQUIRE(pt.ldY == 4 && pt.C >= 1 && pt.c0 + pt.C <= 4, "skinny_wgrad: dY must be rows of 4 floats");
+    NERF_REQUIRE(pt.ldX % 4 == 0 && ((size_t)pt.X % 16) == 0 && ((size_t)pt.dY % 16) == 0, "skinny_wgrad: rows must be 16-byte aligned");
+    const int blocks = (int)((P32 / 32 < 2048) ? (P32 / 32 > 0 ? P32 / 32 : 1) : 2048);
+    switch (pt.K) {
+        case 256: hipLaunchKernelGGL(skinny_wgrad_kernel<256>, dim3(blocks), dim3(256), 0, stream, pt, P32); break;
+        case 128: hipLaunchKernelGGL(skinny_wgrad_kernel<128>, dim3(blocks), dim3(256), 0, stream, pt, P32); break;
+        case 64: hipLaunchKernelGGL(skinny_wgrad_kernel<64>, dim3(blocks), dim3(256), 0, stream, pt, P32); break;
+        default: return fail(NERF_EINVAL, "skinny_wgrad: unsupported width");
+    }
     return check_launch("skinny_wgrad");
 }
 

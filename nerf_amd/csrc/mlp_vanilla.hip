@@ -314,14 +314,15 @@ extern "C" int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, in
     const int xe_col = skip_h_first ? 256 : 0, h_col = skip_h_first ? 0 : 63;
     WgradParts parts{};
     int n = 0;
-    // ordered by decreasing cost so that the heavy slabs are dispatched first
+    // The narrow parts (4 MFMAs per k-step) wait on memory rather than on the MFMA pipe
+    // and run longer than their MFMA count says: dispatch them first, the wide ones after.
+    parts.part[n++] = wgrad_part_desc(DY(0), 256, XE, 64, grads[0], 63, 0, 63, grads[1], 2);
+    parts.part[n++] = wgrad_part_desc(DY(4), 256, XE, 64, grads[8], 319, xe_col, 63, nullptr, 2);
+    parts.part[n++] = wgrad_part_desc(DYR, 128, FEAT, 256, grads[20], 283, 0, 256, grads[21], 1, DE, 32, 256, 27);
     for (int l = 1; l < 8; ++l)
         parts.part[n++] = wgrad_part_desc(DY(l), 256, H(l - 1), 256, grads[2 * l], l == 4 ? 319 : 256, l == 4 ? h_col : 0, 256,
                                           grads[2 * l + 1], 0);
     parts.part[n++] = wgrad_part_desc(DFEAT, 256, H(7), 256, grads[18], 256, 0, 256, grads[19], 0);
-    parts.part[n++] = wgrad_part_desc(DYR, 128, FEAT, 256, grads[20], 283, 0, 256, grads[21], 1, DE, 32, 256, 27);
-    parts.part[n++] = wgrad_part_desc(DY(0), 256, XE, 64, grads[0], 63, 0, 63, grads[1], 2);
-    parts.part[n++] = wgrad_part_desc(DY(4), 256, XE, 64, grads[8], 319, xe_col, 63, nullptr, 2);
     parts.n = n;
     if (int rc = launch_wgrad(parts, P32, st)) return rc;
 
