@@ -53,7 +53,10 @@ __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16
     constexpr int W = OT >= 4 ? 4 : OT;
     constexpr int V = OT / W;
     constexpr int S = KT * 16;       // k-steps; one step = OT MFMAs sharing one B register
-    constexpr int D = S < 4 ? S : 4;  // steps of weight prefetch kept in flight (L2 latency >> one step)
+#ifndef NERF_RING_DEPTH
+#define NERF_RING_DEPTH 4
+#endif
+    constexpr int D = S < NERF_RING_DEPTH ? S : NERF_RING_DEPTH;  // steps of weight prefetch kept in flight (L2 latency >> one step)
     const wvec* __restrict__ w4 = reinterpret_cast<const wvec*>(wp) + lane * V;
     wvec ring[D][V];
     float4 drain_buf = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -91,6 +94,206 @@ __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16
         for (int ot = 0; ot < OT; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ot], b, acc[ot], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// ------------------------------------------------ shared weight stream ----
+// Weights that arrive through vector loads cost the matrix pipe time: every KiB
+// returned to a SIMD (into registers or, by a direct-to-LDS load, into LDS) holds
+// its MFMAs back by ~22 cycles, which is 7 of 71 cycles per MFMA when each of the
+// four waves of a workgroup loads every weight itself.  LDS reads are free.  So the
+// workgroup copies the weights into LDS once, each wave a quarter, and every wave
+// reads its operands from there.
+//
+// The packed weights of consecutive dense() calls form one stream of chunks of 16
+// k-steps (at most 32 KiB).  Three chunk buffers rotate.  In the middle of chunk g
+// every wave waits for its own copies of chunk g+1, the workgroup meets at a
+// barrier (so chunk g+1 is complete, and nobody reads chunk g-1 any more), and the
+// copies of chunk g+2 go out into the buffer chunk g-1 occupied.  The barrier sits
+// between two MFMA groups with the next operands already requested, so the pipe
+// only sees the skew between the waves.  All four waves must make the same calls.
+//
+// Every LDS access here is asm: the compiler makes each LDS access it knows of
+// wait for all direct-to-LDS copies in flight, and orders loads by its own model.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ f32x4 lds_read4(unsigned addr) {
+    f32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF_BYTES));
+    return r;
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ void lds_write4(unsigned addr, f32x4 v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF_BYTES) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+constexpr int WS_CHUNK_STEPS = 16;
+constexpr int WS_CHUNK_FLOATS = WS_CHUNK_STEPS * 8 * 64;   // largest chunk: 16 k-steps of 8 output tiles (32 KiB)
+constexpr int WS_LDS_FLOATS = 3 * WS_CHUNK_FLOATS;
+constexpr int TILE_LD = 36;                                // row pitch of the 32 x 32 transposition buffer
+constexpr int TILE_LDS_FLOATS = 32 * TILE_LD;
+constexpr int MLP_LDS_FLOATS = WS_LDS_FLOATS + 4 * TILE_LDS_FLOATS;   // per workgroup of 4 waves
+
+__device__ __forceinline__ int wrap3(int x) { return x >= 3 ? x - 3 : x; }
+
+struct WeightStream {
+    float* lds;   // three chunk buffers shared by the workgroup
+    int g3;       // buffer of the chunk the next dense_shared() starts with
+    int wave, lane;
+};
+// The two chunks that follow a layer's own in the stream, as 1 KiB pieces per wave (0 = none).
+struct NextChunks {
+    const float* p0; int pw0;
+    const float* p1; int pw1;
+};
+// The chunks after a layer of N_FLOATS packed floats whose successor has OT_NEXT output tiles
+// (and at least two chunks; the packed layers of a kernel are contiguous in stream order).
+template <int OT_NEXT>
+__device__ __forceinline__ NextChunks next_chunks(const float* after) {
+    constexpr int CHF = WS_CHUNK_STEPS * OT_NEXT * 64;
+    return NextChunks{after, CHF / 1024, after + CHF, CHF / 1024};
+}
+
+// A wave's 32 x 36 float transposition buffer, for writing register tiles (32 points x
+// 32 neurons) to a row-major array as whole 128-byte row segments: ds_write_b128 in the
+// register layout, ds_read_b128 + one 16-byte store per lane in the row layout (lane L:
+// row L/8 of each group of 8 rows, floats 4(L%8)..+3).  Stored straight from the register
+// layout a store instruction touches 32 different 128-byte lines, 32 bytes each.
+struct TileBuf {
+    unsigned wr, rd;   // this lane's LDS byte addresses in the two layouts
+    int row, col;      // this lane's row within a group of 8 and first column, row layout
+};
+__device__ __forceinline__ TileBuf tile_buf(float* lds_wave, int lane) {
+    return TileBuf{lds_addr(lds_wave + (lane & 31) * TILE_LD + 4 * (lane >> 5)),
+                   lds_addr(lds_wave + (lane >> 3) * TILE_LD + 4 * (lane & 7)), lane >> 3, 4 * (lane & 7)};
+}
+// Rows to write underneath a dense_shared() call: its input tiles, to rows0[32][ld = 256].
+struct TileSave {
+    TileBuf tb;
+    float* rows0;   // row 0 of the tile's 32 rows, already offset by this lane's (row, col)
+};
+__device__ __forceinline__ TileSave tile_save(const TileBuf& tb, float* tile_rows0) {
+    return TileSave{tb, tile_rows0 + (size_t)tb.row * 256 + tb.col};
+}
+
+// Write NT register tiles to rows0[32][ld] now (not overlapped with anything).
+template <int NT>
+__device__ __forceinline__ void save_tiles(const TileBuf& tb, float* __restrict__ rows0, int ld, const f32x16 (&a)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        static_for<0, 4>([&](auto cq) {
+            constexpr int q = decltype(cq)::value;
+            lds_write4<32 * q>(tb.wr, f32x4{a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]});
+        });
+        f32x4 v[4];
+        static_for<0, 4>([&](auto ck) { v[ck] = lds_read4<8 * decltype(ck)::value * TILE_LD * 4>(tb.rd); });
+        lgkm_wait();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            asm volatile("" : "+v"(v[k]));
+            *reinterpret_cast<f32x4*>(rows0 + (size_t)(8 * k + tb.row) * ld + 32 * t + tb.col) = v[k];
+        }
+    }
+}
+
+__device__ __forceinline__ void ws_copy_piece(const WeightStream& ws, const float* chunk, float* buf, int q) {
+    const int piece = 4 * q + ws.wave;   // the four waves take pieces 4q..4q+3 together
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(chunk + piece * 256 + ws.lane * 4),
+                                     (__attribute__((address_space(3))) void*)(buf + piece * 256), 16, 0, 0);
+}
+
+// Start the stream: request its first two chunks.  ws_ready() must follow before the first dense_shared().
+__device__ __forceinline__ void ws_prime(WeightStream& ws, const float* c0, int pw0, const float* c1, int pw1) {
+    for (int q = 0; q < pw0; ++q) ws_copy_piece(ws, c0, ws.lds, q);
+    for (int q = 0; q < pw1; ++q) ws_copy_piece(ws, c1, ws.lds + WS_CHUNK_FLOATS, q);
+    ws.g3 = 0;
+}
+__device__ __forceinline__ void ws_ready() {
+    vm_wait<0>();
+    __builtin_amdgcn_s_barrier();
+}
+
+// acc[ot] += W_tile(ot, kt) * in[kt] for all tiles, weights from the stream.  wp: this layer's
+// packed weights [KT][16][64][OT]; nx: what follows them in the stream.
+// DRAIN: also write the input tiles to sv.rows0 (row-major, 256 wide), tile kt during chunk kt.
+template <int KT, int OT, bool DRAIN = false>
+__device__ __forceinline__ void dense_shared(WeightStream& ws, const float* __restrict__ wp, const NextChunks nx,
+                                             const f32x16 (&in)[KT], f32x16 (&acc)[OT],
+                                             TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr}) {
+    static_assert(OT % 4 == 0, "operands are read 16 bytes at a time");
+    constexpr int STEP = OT * 64, CHF = WS_CHUNK_STEPS * STEP, PW = CHF / 1024, V = OT / 4;
+    f32x4 a0[V], a1[V];
+    f32x4 dbuf = {0.f, 0.f, 0.f, 0.f};
+    static_for<0, KT>([&](auto ci) {
+        constexpr int i = decltype(ci)::value;
+        const int b0 = wrap3(ws.g3 + i % 3);
+        const unsigned rd = lds_addr(ws.lds + b0 * WS_CHUNK_FLOATS) + ws.lane * (OT * 4);
+        const unsigned rd_next = lds_addr(ws.lds + wrap3(b0 + 1) * WS_CHUNK_FLOATS) + ws.lane * (OT * 4);
+        float* buf2 = ws.lds + wrap3(b0 + 2) * WS_CHUNK_FLOATS;
+        if constexpr (i == 0) static_for<0, V>([&](auto v) { a0[v] = lds_read4<decltype(v)::value * 16>(rd); });
+        static_for<0, WS_CHUNK_STEPS>([&](auto cj) {
+            constexpr int j = decltype(cj)::value;
+            constexpr int s = WS_CHUNK_STEPS * i + j;
+            f32x4(&cur)[V] = (s % 2 == 0) ? a0 : a1;
+            f32x4(&nxt)[V] = (s % 2 == 0) ? a1 : a0;
+            // Schedule of a k-step: wait for its operands (requested a whole step ago), its
+            // first MFMA, then the requests for the next step, the copies and the row
+            // traffic, then the other MFMAs.  Operands pass through an empty asm so that no
+            // use of them moves above the wait, accumulators so that no MFMA sinks.
+            lgkm_wait();
+#pragma unroll
+            for (int v = 0; v < V; ++v) asm volatile("" : "+v"(cur[v]));
+            if constexpr (DRAIN) asm volatile("" : "+v"(dbuf));
+            const float b = in[i][j];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][0], b, acc[0], 0, 0, 0);
+            asm volatile("" : "+a"(acc[0]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j == WS_CHUNK_STEPS / 2) ws_ready();
+            if constexpr (j >= WS_CHUNK_STEPS / 2) {
+                constexpr int q = j - WS_CHUNK_STEPS / 2;
+                if constexpr (i + 2 < KT) {
+                    if constexpr (q < PW) ws_copy_piece(ws, wp + (i + 2) * CHF, buf2, q);
+                } else if constexpr (i + 2 - KT == 0) {
+                    if (q < nx.pw0) ws_copy_piece(ws, nx.p0, buf2, q);
+                } else {
+                    if (q < nx.pw1) ws_copy_piece(ws, nx.p1, buf2, q);
+                }
+            }
+            if constexpr (j + 1 < WS_CHUNK_STEPS) {
+                static_for<0, V>([&](auto v) { nxt[v] = lds_read4<(j + 1) * STEP * 4 + decltype(v)::value * 16>(rd); });
+            } else if constexpr (i + 1 < KT) {
+                static_for<0, V>([&](auto v) { nxt[v] = lds_read4<decltype(v)::value * 16>(rd_next); });
+            }
+            if constexpr (DRAIN) {
+                if constexpr (j == 0) {
+                    static_for<0, 4>([&](auto cq) {
+                        constexpr int q = decltype(cq)::value;
+                        lds_write4<32 * q>(sv.tb.wr, f32x4{in[i][4 * q], in[i][4 * q + 1], in[i][4 * q + 2], in[i][4 * q + 3]});
+                    });
+                }
+                if constexpr (j >= 2 && j <= 11 && (j - 2) % 3 == 0) dbuf = lds_read4<8 * ((j - 2) / 3) * TILE_LD * 4>(sv.tb.rd);
+                if constexpr (j >= 3 && j <= 12 && (j - 3) % 3 == 0)
+                    *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * ((j - 3) / 3)) * 256 + 32 * i) = dbuf;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ot = 1; ot < OT; ++ot) {
+                acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[ot / 4][ot % 4], b, acc[ot], 0, 0, 0);
+                asm volatile("" : "+a"(acc[ot]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+    ws.g3 = wrap3(ws.g3 + KT % 3);
 }
 
 // acc tiles <- per-neuron vector v[32*t + rowmap(r,h)] (bias as the initial accumulator).

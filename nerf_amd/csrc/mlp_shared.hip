@@ -144,9 +144,6 @@ __device__ __forceinline__ void lds_wait(float (&a)[NA], float (&b)[NB]) {
 #pragma unroll
     for (int k = 0; k < NB; ++k) asm volatile("" : "+v"(b[k]));
 }
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
-}
 
 // LDS byte addresses of this lane's operand rows at k-step 0 of a chunk buffer.
 struct WgradRows {

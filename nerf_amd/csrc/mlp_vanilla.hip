@@ -4,7 +4,7 @@
 // Forward: one wavefront per 32 points; positional encodings are computed in
 // registers, every layer is a chain of exact-f32 MFMAs whose accumulators become
 // the next layer's B operands (see mlp_common.h), weights stream from the
-// packed buffer (L2-resident, 2.4 MB).  For training the activations are written
+// packed buffer (L2-resident, 2.4 MB) through LDS, copied once per workgroup.  For training the activations are written
 // row-major for the weight-gradient GEMMs plus one ReLU bit per neuron for the
 // backward-data kernel.
 // Backward: (1) a fused backward-data chain in the same register layout that
@@ -54,71 +54,81 @@ constexpr int PER_POINT2 = DOUT4 + 4;
 
 struct TileIdx {
     long long tile, gp, lp, P32;
-    int lane, p, h;
+    int lane, p, h, wave;
     bool valid;
 };
 
-__device__ __forceinline__ bool tile_index(long long P, TileIdx& ix) {
+// One wave per 32 points.  The waves of a workgroup meet at barriers inside the
+// dense layers, so a wave whose tile lies beyond the last one does not leave: it
+// recomputes the last tile and stores the same values to the same places.
+__device__ __forceinline__ void tile_index(long long P, TileIdx& ix) {
     ix.lane = threadIdx.x & 63;
-    ix.tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    ix.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long last = (P - 1) / 32;
+    const long long tile = (long long)blockIdx.x * 4 + ix.wave;
+    ix.tile = tile < last ? tile : last;
     ix.p = ix.lane & 31;
     ix.h = ix.lane >> 5;
     ix.gp = ix.tile * 32 + ix.p;
     ix.valid = ix.gp < P;
     ix.lp = ix.valid ? ix.gp : P - 1;
     ix.P32 = (P + 31) / 32 * 32;
-    return ix.tile * 32 < P;
 }
+
+constexpr NextChunks NO_CHUNKS{nullptr, 0, nullptr, 0};
 
 template <bool SAVE>
 __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dirs,
                                                           long long P, const float* __restrict__ pk,
                                                           float* __restrict__ rgb, float* __restrict__ sigma,
                                                           float* __restrict__ ws, int dirs_div) {
-    __shared__ __attribute__((aligned(16))) float stage[4 * STORE_LDS_FLOATS_PER_WAVE];
-    float* lds_wave = stage + (threadIdx.x >> 6) * STORE_LDS_FLOATS_PER_WAVE;
+    __shared__ __attribute__((aligned(16))) float lds[MLP_LDS_FLOATS];
     TileIdx ix;
-    if (!tile_index(P, ix)) return;
+    tile_index(P, ix);
     const int lane = ix.lane, h = ix.h;
+    WeightStream wst{lds, 0, ix.wave, lane};
+    const TileBuf tb = tile_buf(lds + WS_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
+    // the weight stream runs through the packed layers in the order they are used
+    ws_prime(wst, pk + vp::F_L0, 8, pk + vp::F_L0 + WS_CHUNK_FLOATS, 8);
     const float x0 = x[3 * ix.lp], x1 = x[3 * ix.lp + 1], x2 = x[3 * ix.lp + 2];
     uint4* mask_out = SAVE ? reinterpret_cast<uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane : nullptr;
 
     f32x16 xe[2];
     pe_tiles<2>(xe, x0, x1, x2, 10, h);
-    if (SAVE) store_tile_rows<2>(lds_wave, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64, xe, lane);
+    if (SAVE) save_tiles<2>(tb, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64, xe);
+    ws_ready();
 
     f32x16 hc[8], acc[8];
-    // Training: the activations of layer l are parked in LDS at the layer boundary and
-    // written out row by row underneath the MFMAs of layer l+1 (see PendingRows).
-    auto rows_of = [&](int section) { return ws + ix.P32 * section + ix.tile * 32 * 256; };
+    // Training: the activations of layer l are the input tiles of layer l+1, which writes
+    // them out row by row underneath its MFMAs (see TileSave).
+    auto rows_of = [&](int section) { return tile_save(tb, ws + ix.P32 * section + ix.tile * 32 * 256); };
     auto finish_layer = [&](int l) {
         relu_tiles<8>(acc);
 #pragma unroll
         for (int t = 0; t < 8; ++t) hc[t] = acc[t];
-        if (SAVE) {
-            stage_tile(lds_wave, hc, lane);
-            mask_out[l * 64] = relu_bits<8>(hc);
-        }
+        if (SAVE) mask_out[l * 64] = relu_bits<8>(hc);
     };
     // layer 0
     fill_rows<8>(acc, pk + vp::S_BIAS, h);
-    dense<2, 8>(pk + vp::F_L0, xe, acc, lane);
+    dense_shared<2, 8>(wst, pk + vp::F_L0, next_chunks<8>(pk + vp::F_L1), xe, acc);
     finish_layer(0);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
+        const float* wp = pk + vp::F_L1 + (l - 1) * vp::T88;   // followed by the next layer, or by the layer-4 x columns
         fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense<8, 8, SAVE>(pk + vp::F_L1 + (l - 1) * vp::T88, hc, acc, lane, PendingRows{lds_wave, rows_of(vw::H + 256 * (l - 1))});
+        dense_shared<8, 8, SAVE>(wst, wp, next_chunks<8>(wp + vp::T88), hc, acc, rows_of(vw::H + 256 * (l - 1)));
         finish_layer(l);
     }
     // skip connection: the layer-4 input is [x_enc | h] (either column order, see the packing)
     fill_rows<8>(acc, pk + vp::S_BIAS + 256 * 4, h);
-    dense<2, 8>(pk + vp::F_L4X, xe, acc, lane);
-    dense<8, 8, SAVE>(pk + vp::F_L4H, hc, acc, lane, PendingRows{lds_wave, rows_of(vw::H + 256 * 3)});
+    dense_shared<2, 8>(wst, pk + vp::F_L4X, next_chunks<8>(pk + vp::F_L4H), xe, acc);
+    dense_shared<8, 8, SAVE>(wst, pk + vp::F_L4H, next_chunks<8>(pk + vp::F_L5), hc, acc, rows_of(vw::H + 256 * 3));
     finish_layer(4);
 #pragma unroll 1
     for (int l = 5; l < 8; ++l) {
+        const float* wp = pk + vp::F_L5 + (l - 5) * vp::T88;   // followed by the next layer, or by the feature layer
         fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense<8, 8, SAVE>(pk + vp::F_L5 + (l - 5) * vp::T88, hc, acc, lane, PendingRows{lds_wave, rows_of(vw::H + 256 * (l - 1))});
+        dense_shared<8, 8, SAVE>(wst, wp, next_chunks<8>(wp + vp::T88), hc, acc, rows_of(vw::H + 256 * (l - 1)));
         finish_layer(l);
     }
     // density head: softplus(w.h + b)   (NeRF.py:90)
@@ -126,22 +136,19 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(sp);
     // feature layer (no activation)      (NeRF.py:95)
     fill_rows<8>(acc, pk + vp::S_BF, h);
-    dense<8, 8, SAVE>(pk + vp::F_FEAT, hc, acc, lane, PendingRows{lds_wave, rows_of(vw::H + 256 * 7)});
+    dense_shared<8, 8, SAVE>(wst, pk + vp::F_FEAT, next_chunks<4>(pk + vp::F_RGB0F), hc, acc, rows_of(vw::H + 256 * 7));
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
     const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
     pe_tiles<1>(de, dirs[3 * dr], dirs[3 * dr + 1], dirs[3 * dr + 2], 4, h);
-    if (SAVE) {
-        store_tile_rows<1>(lds_wave, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32, de, lane);
-        stage_tile(lds_wave, acc, lane);   // the feature rows leave underneath the colour layer
-    }
+    if (SAVE) save_tiles<1>(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32, de);
     f32x16 hr[4];
     fill_rows<4>(hr, pk + vp::S_B1, h);
-    dense<8, 4, SAVE>(pk + vp::F_RGB0F, acc, hr, lane, PendingRows{lds_wave, rows_of(vw::FEAT)});
-    dense<1, 4>(pk + vp::F_RGB0D, de, hr, lane);
+    dense_shared<8, 4, SAVE>(wst, pk + vp::F_RGB0F, NextChunks{pk + vp::F_RGB0D, 4, nullptr, 0}, acc, hr, rows_of(vw::FEAT));
+    dense_shared<1, 4>(wst, pk + vp::F_RGB0D, NO_CHUNKS, de, hr);
     relu_tiles<4>(hr);
     if (SAVE) {
-        store_tile_rows<4>(lds_wave, ws + ix.P32 * vw::HR + ix.tile * 32 * 128, 128, hr, lane);
+        save_tiles<4>(tb, ws + ix.P32 * vw::HR + ix.tile * 32 * 128, 128, hr);
         mask_out[8 * 64] = relu_bits<4>(hr);
     }
 #pragma unroll
@@ -158,11 +165,13 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
                                                                const float* __restrict__ rgb,
                                                                const float* __restrict__ sigma,
                                                                const float* __restrict__ ws, float* __restrict__ ws2) {
-    __shared__ __attribute__((aligned(16))) float stage[4 * STORE_LDS_FLOATS_PER_WAVE];
-    float* lds_wave = stage + (threadIdx.x >> 6) * STORE_LDS_FLOATS_PER_WAVE;
+    __shared__ __attribute__((aligned(16))) float lds[MLP_LDS_FLOATS];
     TileIdx ix;
-    if (!tile_index(P, ix)) return;
+    tile_index(P, ix);
     const int lane = ix.lane, h = ix.h;
+    WeightStream wst{lds, 0, ix.wave, lane};
+    const TileBuf tb = tile_buf(lds + WS_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
+    ws_prime(wst, pk + vp::B_RGB0, 8, pk + vp::B_RGB0 + WS_CHUNK_FLOATS, 8);
     const uint4* mask_in = reinterpret_cast<const uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane;
     float dpre[3], dps = 0.0f;
 #pragma unroll
@@ -194,16 +203,16 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
             dyr[t][4 * q + 3] = s.w;
         }
     apply_bits<4>(dyr, mask_in[8 * 64]);
-    store_tile_rows<4>(lds_wave, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128, dyr, lane);
+    save_tiles<4>(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128, dyr);
+    ws_ready();
 
-    // Each 256-wide gradient tile is parked in LDS and written out underneath the next layer's MFMAs.
-    auto rows_of = [&](int section) { return ws2 + ix.P32 * section + ix.tile * 32 * 256; };
+    // Each 256-wide gradient tile set is the input of the next layer down, which writes it out underneath its MFMAs.
+    auto rows_of = [&](int section) { return tile_save(tb, ws2 + ix.P32 * section + ix.tile * 32 * 256); };
     f32x16 a[8], b[8];
     zero_tiles<8>(a);
-    dense<4, 8>(pk + vp::B_RGB0, dyr, a, lane);   // d feat
-    stage_tile(lds_wave, a, lane);
+    dense_shared<4, 8>(wst, pk + vp::B_RGB0, next_chunks<8>(pk + vp::B_FEAT), dyr, a);   // d feat
     zero_tiles<8>(b);
-    dense<8, 8, true>(pk + vp::B_FEAT, a, b, lane, PendingRows{lds_wave, rows_of(vw::DFEAT)});   // d h7 through the feature layer ...
+    dense_shared<8, 8, true>(wst, pk + vp::B_FEAT, next_chunks<8>(pk + vp::B_L7), a, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
 #pragma unroll
     for (int t = 0; t < 8; ++t)                    // ... plus the density head
 #pragma unroll
@@ -215,17 +224,18 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
             b[t][4 * q + 3] = fmaf(w.w, dps, b[t][4 * q + 3]);
         }
     apply_bits<8>(b, mask_in[7 * 64]);
-    stage_tile(lds_wave, b, lane);
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                 // d h_{l-1} = W_l^T d y_l (h columns only at l = 4)
+        const float* wp = pk + vp::B_L7 + (7 - l) * vp::T88;
+        NextChunks nx = next_chunks<8>(wp + vp::T88);
+        if (l == 1) nx = NO_CHUNKS;
         zero_tiles<8>(a);
-        dense<8, 8, true>(pk + vp::B_L7 + (7 - l) * vp::T88, b, a, lane, PendingRows{lds_wave, rows_of(vw::DY + l * 256)});
+        dense_shared<8, 8, true>(wst, wp, nx, b, a, rows_of(vw::DY + l * 256));
         apply_bits<8>(a, mask_in[(l - 1) * 64]);
-        stage_tile(lds_wave, a, lane);
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[t] = a[t];
     }
-    drain_tile_rows<8>(lds_wave, rows_of(vw::DY), 256, lane);
+    save_tiles<8>(tb, ws2 + ix.P32 * vw::DY + ix.tile * 32 * 256, 256, b);
 }
 
 }  // namespace nerf
