@@ -175,13 +175,14 @@ __device__ __forceinline__ TileBuf tile_buf(float* lds_wave, int lane) {
     return TileBuf{lds_addr(lds_wave + (lane & 31) * TILE_LD + 4 * (lane >> 5)),
                    lds_addr(lds_wave + (lane >> 3) * TILE_LD + 4 * (lane & 7)), lane >> 3, 4 * (lane & 7)};
 }
-// Rows to write underneath a dense_shared() call: its input tiles, to rows0[32][ld = 256].
+// Rows to write underneath a dense_shared() call: its input tiles, to rows0[32][ld].
 struct TileSave {
     TileBuf tb;
     float* rows0;   // row 0 of the tile's 32 rows, already offset by this lane's (row, col)
+    int ld;
 };
-__device__ __forceinline__ TileSave tile_save(const TileBuf& tb, float* tile_rows0) {
-    return TileSave{tb, tile_rows0 + (size_t)tb.row * 256 + tb.col};
+__device__ __forceinline__ TileSave tile_save(const TileBuf& tb, float* tile_rows0, int ld = 256) {
+    return TileSave{tb, tile_rows0 + (size_t)tb.row * ld + tb.col, ld};
 }
 
 // Write NT register tiles to rows0[32][ld] now (not overlapped with anything).
@@ -216,18 +217,22 @@ __device__ __forceinline__ void ws_prime(WeightStream& ws, const float* c0, int 
     for (int q = 0; q < pw1; ++q) ws_copy_piece(ws, c1, ws.lds + WS_CHUNK_FLOATS, q);
     ws.g3 = 0;
 }
+// YOUNGER: vector memory operations this wave has issued after its last copy (they complete in
+// issue order, so the wait may leave that many in flight; waiting for a store just issued costs
+// its whole trip to memory).
+template <int YOUNGER = 0>
 __device__ __forceinline__ void ws_ready() {
-    vm_wait<0>();
+    vm_wait<YOUNGER>();
     __builtin_amdgcn_s_barrier();
 }
 
 // acc[ot] += W_tile(ot, kt) * in[kt] for all tiles, weights from the stream.  wp: this layer's
 // packed weights [KT][16][64][OT]; nx: what follows them in the stream.
-// DRAIN: also write the input tiles to sv.rows0 (row-major, 256 wide), tile kt during chunk kt.
+// DRAIN: also write the input tiles to sv.rows0 (row-major), tile kt during chunk kt.
 template <int KT, int OT, bool DRAIN = false>
 __device__ __forceinline__ void dense_shared(WeightStream& ws, const float* __restrict__ wp, const NextChunks nx,
                                              const f32x16 (&in)[KT], f32x16 (&acc)[OT],
-                                             TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr}) {
+                                             TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
     static_assert(OT % 4 == 0, "operands are read 16 bytes at a time");
     constexpr int STEP = OT * 64, CHF = WS_CHUNK_STEPS * STEP, PW = CHF / 1024, V = OT / 4;
     f32x4 a0[V], a1[V];
@@ -257,7 +262,7 @@ __device__ __forceinline__ void dense_shared(WeightStream& ws, const float* __re
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][0], b, acc[0], 0, 0, 0);
             asm volatile("" : "+a"(acc[0]));
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j == WS_CHUNK_STEPS / 2) ws_ready();
+            if constexpr (j == WS_CHUNK_STEPS / 2) ws_ready<DRAIN ? 2 : 0>();   // DRAIN: the row stores of steps 3 and 6
             if constexpr (j >= WS_CHUNK_STEPS / 2) {
                 constexpr int q = j - WS_CHUNK_STEPS / 2;
                 if constexpr (i + 2 < KT) {
@@ -282,7 +287,7 @@ __device__ __forceinline__ void dense_shared(WeightStream& ws, const float* __re
                 }
                 if constexpr (j >= 2 && j <= 11 && (j - 2) % 3 == 0) dbuf = lds_read4<8 * ((j - 2) / 3) * TILE_LD * 4>(sv.tb.rd);
                 if constexpr (j >= 3 && j <= 12 && (j - 3) % 3 == 0)
-                    *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * ((j - 3) / 3)) * 256 + 32 * i) = dbuf;
+                    *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * ((j - 3) / 3)) * sv.ld + 32 * i) = dbuf;
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
 
     f32x16 xe[2];
     pe_tiles<2>(xe, x0, x1, x2, 10, h);
-    if (SAVE) save_tiles<2>(tb, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64, xe);
     ws_ready();
 
     f32x16 hc[8], acc[8];
@@ -110,7 +109,8 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     };
     // layer 0
     fill_rows<8>(acc, pk + vp::S_BIAS, h);
-    dense_shared<2, 8>(wst, pk + vp::F_L0, next_chunks<8>(pk + vp::F_L1), xe, acc);
+    dense_shared<2, 8, SAVE>(wst, pk + vp::F_L0, next_chunks<8>(pk + vp::F_L1), xe, acc,
+                             tile_save(tb, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64));
     finish_layer(0);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
@@ -141,11 +141,10 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     f32x16 de[1];
     const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
     pe_tiles<1>(de, dirs[3 * dr], dirs[3 * dr + 1], dirs[3 * dr + 2], 4, h);
-    if (SAVE) save_tiles<1>(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32, de);
     f32x16 hr[4];
     fill_rows<4>(hr, pk + vp::S_B1, h);
     dense_shared<8, 4, SAVE>(wst, pk + vp::F_RGB0F, NextChunks{pk + vp::F_RGB0D, 4, nullptr, 0}, acc, hr, rows_of(vw::FEAT));
-    dense_shared<1, 4>(wst, pk + vp::F_RGB0D, NO_CHUNKS, de, hr);
+    dense_shared<1, 4, SAVE>(wst, pk + vp::F_RGB0D, NO_CHUNKS, de, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
     relu_tiles<4>(hr);
     if (SAVE) {
         save_tiles<4>(tb, ws + ix.P32 * vw::HR + ix.tile * 32 * 128, 128, hr);
@@ -203,14 +202,14 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
             dyr[t][4 * q + 3] = s.w;
         }
     apply_bits<4>(dyr, mask_in[8 * 64]);
-    save_tiles<4>(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128, dyr);
     ws_ready();
 
     // Each 256-wide gradient tile set is the input of the next layer down, which writes it out underneath its MFMAs.
     auto rows_of = [&](int section) { return tile_save(tb, ws2 + ix.P32 * section + ix.tile * 32 * 256); };
     f32x16 a[8], b[8];
     zero_tiles<8>(a);
-    dense_shared<4, 8>(wst, pk + vp::B_RGB0, next_chunks<8>(pk + vp::B_FEAT), dyr, a);   // d feat
+    dense_shared<4, 8, true>(wst, pk + vp::B_RGB0, next_chunks<8>(pk + vp::B_FEAT), dyr, a,
+                             tile_save(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128));   // d feat
     zero_tiles<8>(b);
     dense_shared<8, 8, true>(wst, pk + vp::B_FEAT, next_chunks<8>(pk + vp::B_L7), a, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
 #pragma unroll
