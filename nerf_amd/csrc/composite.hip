@@ -1,5 +1,5 @@
 // Alpha compositing (Camera.volume_render, src/Camera.py:143-183) and its
-// backward for gfx950.  One wavefront owns one ray; lane l holds IPL consecutive
+// backward for gfx950.  One wavefront owns a ray at a time; lane l holds IPL consecutive
 // samples, the exclusive transmittance product is a lane-local prefix followed
 // by a 64-lane shuffle scan, and the backward uses the mirrored suffix scan.
 // Bandwidth-bound: 20 B/sample in, 4 B/sample out (forward).
@@ -11,45 +11,77 @@ namespace nerf {
 
 constexpr int CMP_WAVES = 4;  // rays per workgroup
 
-// Exclusive prefix product across the wave of each lane's total.
+// Exclusive prefix product across the wave of each lane's total: inclusive scan inside each
+// row of 16 lanes, times the product of the rows before, shifted up by one lane.
 __device__ __forceinline__ float wave_excl_prod(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(v, d, 64);
-        if (lane >= d) v *= o;
-    }
-    const float e = __shfl_up(v, 1, 64);
-    return lane == 0 ? 1.0f : e;
+    v *= dpp_move<DPP_ROW_SHR + 1>(1.0f, v);
+    v *= dpp_move<DPP_ROW_SHR + 2>(1.0f, v);
+    v *= dpp_move<DPP_ROW_SHR + 4>(1.0f, v);
+    v *= dpp_move<DPP_ROW_SHR + 8>(1.0f, v);
+    const float r0 = lane_value(v, 15), r1 = lane_value(v, 31), r2 = lane_value(v, 47);
+    const float p1 = r0, p2 = r0 * r1, p3 = p2 * r2;
+    const int row = lane >> 4;
+    v *= row == 0 ? 1.0f : row == 1 ? p1 : row == 2 ? p2 : p3;
+    return dpp_move<DPP_WAVE_SHR1>(1.0f, v);
 }
 
 // Exclusive suffix sum across the wave (sum of the totals of all higher lanes).
 __device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_down(v, d, 64);
-        if (lane + d < 64) v += o;
-    }
-    const float e = __shfl_down(v, 1, 64);
-    return lane == 63 ? 0.0f : e;
+    v += dpp_move<DPP_ROW_SHL + 1>(0.0f, v);
+    v += dpp_move<DPP_ROW_SHL + 2>(0.0f, v);
+    v += dpp_move<DPP_ROW_SHL + 4>(0.0f, v);
+    v += dpp_move<DPP_ROW_SHL + 8>(0.0f, v);
+    const float r1 = lane_value(v, 16), r2 = lane_value(v, 32), r3 = lane_value(v, 48);
+    const float s2 = r3, s1 = r3 + r2, s0 = s1 + r1;
+    const int row = lane >> 4;
+    v += row == 3 ? 0.0f : row == 2 ? s2 : row == 1 ? s1 : s0;
+    return dpp_move<DPP_WAVE_SHL1>(0.0f, v);
 }
 
-// Loads the lane's IPL samples and computes alpha, t = 1-alpha+1e-10, T and w.
-template <int IPL>
+// K consecutive floats as one load (dword, x2, x3 or x4 pieces; 4-byte aligned).
+template <int K>
+struct __attribute__((packed, aligned(4))) FloatRun {
+    float v[K];
+};
+
+// A lane's IPL consecutive samples of one ray: loads, then alpha, t = 1-alpha+1e-10, T and w.
+// FULL: N == 64*IPL, every lane is full and the loads are unconditional vector loads.
+template <int IPL, bool FULL>
 struct RaySlice {
-    float sig[IPL], dist[IPL], alpha[IPL], tr[IPL], T[IPL], w[IPL], zz[IPL];
+    float sig[IPL], dist[IPL], alpha[IPL], tr[IPL], T[IPL], w[IPL], zz[IPL], c[IPL][3];
     bool ok[IPL];
 
-    __device__ __forceinline__ void load(const float* __restrict__ sigma, const float* __restrict__ z, int64_t ray,
-                                         int N, int lane) {
+    __device__ __forceinline__ void load(const float* __restrict__ rgb, const float* __restrict__ sigma,
+                                         const float* __restrict__ z, int64_t ray, int N, int lane) {
+        const int base = lane * IPL;
+        if (FULL) {
+            const FloatRun<IPL> s = *reinterpret_cast<const FloatRun<IPL>*>(sigma + ray * N + base);
+            const FloatRun<IPL> q = *reinterpret_cast<const FloatRun<IPL>*>(z + ray * N + base);
+            const FloatRun<3 * IPL> col = *reinterpret_cast<const FloatRun<3 * IPL>*>(rgb + (ray * N + base) * 3);
+#pragma unroll
+            for (int k = 0; k < IPL; ++k) {
+                ok[k] = true;
+                sig[k] = s.v[k];
+                zz[k] = q.v[k];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) c[k][ch] = col.v[3 * k + ch];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < IPL; ++k) {
+                const int i = base + k;
+                ok[k] = i < N;
+                sig[k] = ok[k] ? sigma[ray * N + i] : 0.0f;
+                zz[k] = ok[k] ? z[ray * N + i] : 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) c[k][ch] = ok[k] ? rgb[(ray * N + i) * 3 + ch] : 0.0f;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void compute(int N, int lane) {
         const int base = lane * IPL;
         float lane_prod = 1.0f;
-#pragma unroll
-        for (int k = 0; k < IPL; ++k) {
-            const int i = base + k;
-            ok[k] = i < N;
-            sig[k] = ok[k] ? sigma[ray * N + i] : 0.0f;
-            zz[k] = ok[k] ? z[ray * N + i] : 0.0f;
-        }
         // z of the next sample: the next register, or the next lane's first one
         const float z_next_lane = __shfl_down(zz[0], 1, 64);
 #pragma unroll
@@ -71,84 +103,138 @@ struct RaySlice {
     }
 };
 
+// A wave takes RPW rays at once, all loads first: a ray of 64 samples is only 1.3 KB,
+// too little in flight per wave to cover the memory latency at 8 waves per SIMD.
 template <int IPL>
+struct RaysPerWave {
+    static constexpr int value = IPL == 1 ? 4 : IPL <= 4 ? 2 : 1;
+};
+
+template <int IPL, bool FULL>
 __global__ __launch_bounds__(CMP_WAVES * 64) void composite_fwd_kernel(
     const float* __restrict__ rgb, const float* __restrict__ sigma, const float* __restrict__ z, int64_t R, int N,
     int white, float* __restrict__ out_rgb, float* __restrict__ weights, float* __restrict__ depth) {
+    constexpr int RPW = RaysPerWave<IPL>::value;
     const int lane = threadIdx.x & 63;
-    const int64_t ray = (int64_t)blockIdx.x * CMP_WAVES + (threadIdx.x >> 6);
-    if (ray >= R) return;  // whole wave leaves together
-    RaySlice<IPL> s;
-    s.load(sigma, z, ray, N, lane);
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, ws = 0.f, dz = 0.f;
+    const int64_t ray0 = ((int64_t)blockIdx.x * CMP_WAVES + (threadIdx.x >> 6)) * RPW;
+    if (ray0 >= R) return;  // whole wave leaves together
+    RaySlice<IPL, FULL> s[RPW];
 #pragma unroll
-    for (int k = 0; k < IPL; ++k) {
-        const int i = lane * IPL + k;
-        if (s.ok[k]) {
-            const float* c = rgb + (ray * N + i) * 3;
-            c0 += s.w[k] * c[0];
-            c1 += s.w[k] * c[1];
-            c2 += s.w[k] * c[2];
-            ws += s.w[k];
-            dz += s.w[k] * s.zz[k];
-            weights[ray * N + i] = s.w[k];
+    for (int q = 0; q < RPW; ++q) s[q].load(rgb, sigma, z, min(ray0 + q, R - 1), N, lane);
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int64_t ray = ray0 + q;
+        if (ray >= R) break;  // uniform over the wave
+        s[q].compute(N, lane);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, ws = 0.f, dz = 0.f;
+        float wout[IPL];
+#pragma unroll
+        for (int k = 0; k < IPL; ++k) {
+            wout[k] = s[q].w[k];
+            if (s[q].ok[k]) {
+                c0 += s[q].w[k] * s[q].c[k][0];
+                c1 += s[q].w[k] * s[q].c[k][1];
+                c2 += s[q].w[k] * s[q].c[k][2];
+                ws += s[q].w[k];
+                dz += s[q].w[k] * s[q].zz[k];
+            }
         }
-    }
-    c0 = wave_sum(c0);
-    c1 = wave_sum(c1);
-    c2 = wave_sum(c2);
-    ws = wave_sum(ws);
-    if (depth) dz = wave_sum(dz);
-    if (lane == 0) {
-        const float bg = white ? 1.0f - ws : 0.0f;  // src/Camera.py:175-176
-        out_rgb[ray * 3 + 0] = c0 + bg;
-        out_rgb[ray * 3 + 1] = c1 + bg;
-        out_rgb[ray * 3 + 2] = c2 + bg;
-        if (depth) depth[ray] = dz;
+        if (FULL) {
+            FloatRun<IPL> o;
+#pragma unroll
+            for (int k = 0; k < IPL; ++k) o.v[k] = wout[k];
+            *reinterpret_cast<FloatRun<IPL>*>(weights + ray * N + lane * IPL) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < IPL; ++k)
+                if (s[q].ok[k]) weights[ray * N + lane * IPL + k] = wout[k];
+        }
+        c0 = wave_sum(c0);
+        c1 = wave_sum(c1);
+        c2 = wave_sum(c2);
+        ws = wave_sum(ws);
+        if (depth) dz = wave_sum(dz);
+        if (lane == 0) {
+            const float bg = white ? 1.0f - ws : 0.0f;  // src/Camera.py:175-176
+            out_rgb[ray * 3 + 0] = c0 + bg;
+            out_rgb[ray * 3 + 1] = c1 + bg;
+            out_rgb[ray * 3 + 2] = c2 + bg;
+            if (depth) depth[ray] = dz;
+        }
     }
 }
 
 // dL/dalpha_i = g_i T_i - (sum_{k>i} g_k w_k) / t_i with g_i = dL/dw_i
 // (direct + through colour, background and depth); dL/dsigma_i = dalpha_i *
 // dist_i * exp(-sigma_i dist_i); dL/drgb_i = w_i * dL/dC.
-template <int IPL>
+template <int IPL, bool FULL>
 __global__ __launch_bounds__(CMP_WAVES * 64) void composite_bwd_kernel(
     const float* __restrict__ rgb, const float* __restrict__ sigma, const float* __restrict__ z,
     const float* __restrict__ d_out, const float* __restrict__ d_weights, const float* __restrict__ d_depth, int64_t R,
     int N, int white, float* __restrict__ d_rgb, float* __restrict__ d_sigma) {
+    constexpr int RPW = RaysPerWave<IPL>::value;
     const int lane = threadIdx.x & 63;
-    const int64_t ray = (int64_t)blockIdx.x * CMP_WAVES + (threadIdx.x >> 6);
-    if (ray >= R) return;
-    RaySlice<IPL> s;
-    s.load(sigma, z, ray, N, lane);
-    const float g0 = d_out[ray * 3 + 0], g1 = d_out[ray * 3 + 1], g2 = d_out[ray * 3 + 2];
-    const float gbg = white ? -((g0 + g1) + g2) : 0.0f;
-    const float gdz = d_depth ? d_depth[ray] : 0.0f;
-    float g[IPL], suf[IPL];
-    float lane_sum = 0.0f;
+    const int64_t ray0 = ((int64_t)blockIdx.x * CMP_WAVES + (threadIdx.x >> 6)) * RPW;
+    if (ray0 >= R) return;
+    RaySlice<IPL, FULL> s[RPW];
+    float dw[RPW][IPL];
 #pragma unroll
-    for (int k = IPL - 1; k >= 0; --k) {
-        const int i = lane * IPL + k;
-        g[k] = 0.0f;
-        if (s.ok[k]) {
-            const float* c = rgb + (ray * N + i) * 3;
-            g[k] = ((g0 * c[0] + g1 * c[1]) + g2 * c[2]) + gbg + gdz * s.zz[k];
-            if (d_weights) g[k] += d_weights[ray * N + i];
-            float* dc = d_rgb + (ray * N + i) * 3;
-            dc[0] = s.w[k] * g0;
-            dc[1] = s.w[k] * g1;
-            dc[2] = s.w[k] * g2;
+    for (int q = 0; q < RPW; ++q) {
+        const int64_t ray = min(ray0 + q, R - 1);
+        s[q].load(rgb, sigma, z, ray, N, lane);
+#pragma unroll
+        for (int k = 0; k < IPL; ++k) {
+            const int i = lane * IPL + k;
+            dw[q][k] = (d_weights && (FULL || i < N)) ? d_weights[ray * N + i] : 0.0f;
         }
-        suf[k] = lane_sum;  // lane-local exclusive suffix
-        lane_sum += g[k] * s.w[k];
     }
-    const float after = wave_excl_suffix_sum(lane_sum, lane);
 #pragma unroll
-    for (int k = 0; k < IPL; ++k) {
-        const int i = lane * IPL + k;
-        if (s.ok[k]) {
-            const float dalpha = g[k] * s.T[k] - (after + suf[k]) / s.tr[k];
-            d_sigma[ray * N + i] = dalpha * s.dist[k] * expf(-s.sig[k] * s.dist[k]);
+    for (int q = 0; q < RPW; ++q) {
+        const int64_t ray = ray0 + q;
+        if (ray >= R) break;
+        s[q].compute(N, lane);
+        const float g0 = d_out[ray * 3 + 0], g1 = d_out[ray * 3 + 1], g2 = d_out[ray * 3 + 2];
+        const float gbg = white ? -((g0 + g1) + g2) : 0.0f;
+        const float gdz = d_depth ? d_depth[ray] : 0.0f;
+        float g[IPL], suf[IPL];
+        FloatRun<3 * IPL> dc;
+        float lane_sum = 0.0f;
+#pragma unroll
+        for (int k = IPL - 1; k >= 0; --k) {
+            g[k] = 0.0f;
+            if (s[q].ok[k]) {
+                g[k] = ((g0 * s[q].c[k][0] + g1 * s[q].c[k][1]) + g2 * s[q].c[k][2]) + gbg + gdz * s[q].zz[k];
+                if (d_weights) g[k] += dw[q][k];
+            }
+            dc.v[3 * k + 0] = s[q].w[k] * g0;
+            dc.v[3 * k + 1] = s[q].w[k] * g1;
+            dc.v[3 * k + 2] = s[q].w[k] * g2;
+            suf[k] = lane_sum;  // lane-local exclusive suffix
+            lane_sum += g[k] * s[q].w[k];
+        }
+        if (FULL) {
+            *reinterpret_cast<FloatRun<3 * IPL>*>(d_rgb + (ray * N + lane * IPL) * 3) = dc;
+        } else {
+#pragma unroll
+            for (int k = 0; k < IPL; ++k)
+                if (s[q].ok[k]) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) d_rgb[(ray * N + lane * IPL + k) * 3 + ch] = dc.v[3 * k + ch];
+                }
+        }
+        const float after = wave_excl_suffix_sum(lane_sum, lane);
+        FloatRun<IPL> ds;
+#pragma unroll
+        for (int k = 0; k < IPL; ++k) {
+            const float dalpha = g[k] * s[q].T[k] - (after + suf[k]) / s[q].tr[k];
+            ds.v[k] = dalpha * s[q].dist[k] * expf(-s[q].sig[k] * s[q].dist[k]);
+        }
+        if (FULL) {
+            *reinterpret_cast<FloatRun<IPL>*>(d_sigma + ray * N + lane * IPL) = ds;
+        } else {
+#pragma unroll
+            for (int k = 0; k < IPL; ++k)
+                if (s[q].ok[k]) d_sigma[ray * N + lane * IPL + k] = ds.v[k];
         }
     }
 }
@@ -157,16 +243,21 @@ __global__ __launch_bounds__(CMP_WAVES * 64) void composite_bwd_kernel(
 
 using namespace nerf;
 
+#define CMP_LAUNCH(KERNEL, IPL, ...)                                                                                \
+    do {                                                                                                            \
+        const dim3 grid((unsigned)ceil_div(R, (int64_t)CMP_WAVES * RaysPerWave<IPL>::value)), block(CMP_WAVES * 64);  \
+        if (N == 64 * IPL) hipLaunchKernelGGL((KERNEL<IPL, true>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<IPL, false>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);              \
+    } while (0)
 #define CMP_DISPATCH(KERNEL, ...)                                                                                   \
     do {                                                                                                            \
-        const dim3 grid((unsigned)ceil_div(R, CMP_WAVES)), block(CMP_WAVES * 64);                                    \
         const int ipl = (N + 63) / 64;                                                                              \
-        if (ipl <= 1) hipLaunchKernelGGL(KERNEL<1>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__);              \
-        else if (ipl <= 2) hipLaunchKernelGGL(KERNEL<2>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__);         \
-        else if (ipl <= 3) hipLaunchKernelGGL(KERNEL<3>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__);         \
-        else if (ipl <= 4) hipLaunchKernelGGL(KERNEL<4>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__);         \
-        else if (ipl <= 8) hipLaunchKernelGGL(KERNEL<8>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__);         \
-        else hipLaunchKernelGGL(KERNEL<16>, grid, block, 0, (hipStream_t)stream, __VA_ARGS__);                      \
+        if (ipl <= 1) CMP_LAUNCH(KERNEL, 1, __VA_ARGS__);                                                           \
+        else if (ipl <= 2) CMP_LAUNCH(KERNEL, 2, __VA_ARGS__);                                                      \
+        else if (ipl <= 3) CMP_LAUNCH(KERNEL, 3, __VA_ARGS__);                                                      \
+        else if (ipl <= 4) CMP_LAUNCH(KERNEL, 4, __VA_ARGS__);                                                      \
+        else if (ipl <= 8) CMP_LAUNCH(KERNEL, 8, __VA_ARGS__);                                                      \
+        else CMP_LAUNCH(KERNEL, 16, __VA_ARGS__);                                                                   \
     } while (0)
 
 extern "C" int nerf_composite_fwd(const float* rgb, const float* sigma, const float* z, int64_t R, int N,
