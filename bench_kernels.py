@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 PEAK_HBM_GBS = 8000.0
 
 
-def timeit(fn, iters=20):
+def timeit(fn, iters=50):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -55,9 +55,16 @@ def main():
     z_lin = torch.linspace(2.0, 6.0, N, device=dev)
     f = 1111.11
 
-    t = timeit(lambda: ops.raygen_sample(c2w, f, f, 400.0, 400.0, 800, 800, pix, z_lin, u))
-    report("raygen_sample (64 samples)", R * (4 + 24) + R * N * (4 + 4 + 12), t, "read pix,u; write rays,z,pts")
+    # outputs are allocated once and the C entry points called directly: at 20-50 us per kernel the
+    # Python wrappers (allocation, autograd bookkeeping) would be what is timed
+    lib = L.lib()
+    st = L.stream_of(u)
     o, d, z, pts = ops.raygen_sample(c2w, f, f, 400.0, 400.0, 800, 800, pix, z_lin, u)
+    c2w_c = c2w.contiguous()
+    a_rs = (L.ptr(c2w_c), f, f, 400.0, 400.0, 800, 800, L.ptr(pix), R, L.ptr(z_lin), L.ptr(u), N, L.ptr(o), L.ptr(d), L.ptr(z),
+            L.ptr(pts), st)   # arguments marshalled once: the loop below should time the kernel, not Python
+    t = timeit(lambda: lib.nerf_raygen_sample(*a_rs))
+    report("raygen_sample (64 samples)", R * (4 + 24) + R * N * (4 + 4 + 12), t, "read pix,u; write rays,z,pts")
 
     for n, zz in ((N, z), (NA, torch.sort(torch.rand(R, NA, generator=g) * 4 + 2, dim=-1).values.to(dev))):
         rgb = torch.rand(R, n, 3, generator=g).to(dev)
@@ -67,18 +74,20 @@ def main():
         dep = torch.empty(R, device=dev)
         lib = L.lib()
         st = L.stream_of(rgb)
-        t = timeit(lambda: L.check(lib.nerf_composite_fwd(L.ptr(rgb), L.ptr(sigma), L.ptr(zz), R, n, 1, L.ptr(out),
-                                                          L.ptr(w), L.ptr(dep), st), "fwd"))
+        a_cf = (L.ptr(rgb), L.ptr(sigma), L.ptr(zz), R, n, 1, L.ptr(out), L.ptr(w), L.ptr(dep), st)
+        t = timeit(lambda: lib.nerf_composite_fwd(*a_cf))
         report("composite_fwd (%d samples)" % n, R * n * 24 + R * 16, t, "read rgb,sigma,z; write weights,colour,depth")
         d_out = torch.randn(R, 3, generator=g).to(dev)
         d_rgb, d_sig = torch.empty_like(rgb), torch.empty_like(sigma)
-        t = timeit(lambda: L.check(lib.nerf_composite_bwd(L.ptr(rgb), L.ptr(sigma), L.ptr(zz), L.ptr(d_out), None, None, R,
-                                                          n, 1, L.ptr(d_rgb), L.ptr(d_sig), st), "bwd"))
+        a_cb = (L.ptr(rgb), L.ptr(sigma), L.ptr(zz), L.ptr(d_out), None, None, R, n, 1, L.ptr(d_rgb), L.ptr(d_sig), st)
+        t = timeit(lambda: lib.nerf_composite_bwd(*a_cb))
         report("composite_bwd (%d samples)" % n, R * n * 36 + R * 12, t, "read rgb,sigma,z,d_out; write d_rgb,d_sigma")
         if n == N:
             wts = w.clone()
 
-    t = timeit(lambda: ops.pdf_sample(o, d, z, wts, uf))
+    z_fine, idx, z_all, pts_all = ops.pdf_sample(o, d, z, wts, uf)
+    a_ps = (L.ptr(o), L.ptr(d), L.ptr(z), L.ptr(wts), L.ptr(uf), R, N, NF, L.ptr(z_fine), L.ptr(idx), L.ptr(z_all), L.ptr(pts_all), st)
+    t = timeit(lambda: lib.nerf_pdf_sample(*a_ps))
     report("pdf_sample (64 -> +128)", R * (N * 8 + NF * 4 + 24) + R * NA * 16 + R * NF * 4, t,
            "read z,weights,u,rays; write z_fine,z_all,pts")
 

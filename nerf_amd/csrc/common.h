@@ -1,5 +1,6 @@
 // Shared host-side helpers for libnerf_hip.so (gfx950 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdint>
@@ -33,6 +34,16 @@ inline int check_launch(const char* what) {
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr int WAVE = 64;
+
+// Compile-time loop: f(std::integral_constant<int, I>) for I in [B, E), so that the
+// loop index can be used as a template argument.
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 // ---- wavefront primitives (64 lanes) ------------------------------------
 // Cross-lane moves by DPP (data-parallel primitives: a lane permutation applied to a VALU

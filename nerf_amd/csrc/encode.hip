@@ -70,23 +70,30 @@ __global__ void hashgrid_fwd_kernel(const float* __restrict__ x, int64_t P, Hash
     *reinterpret_cast<float2*>(out + p * (2 * levels) + 2 * l) = make_float2(r[0], r[1]);
 }
 
-// d table[row(corner)] += weight(corner) * d_out, weight = product of (w or 1-w).
+// d table[row(corner)][f] += weight(corner) * d_out[f], weight = product of (w or 1-w).
+// Scattered float atomics are executed line by line at the memory side, about 20 G lines/s
+// however few lanes of an instruction share a line.  Four lanes share a point: lane bit 0 is
+// the feature, bit 1 the x offset of the corner, so the (up to) four adds that fall into one
+// 16-byte stretch of the table (both features of rows r and r+1: the hash is linear in x)
+// travel in one instruction and, unless the row wraps, in one line.
 __global__ void hashgrid_bwd_kernel(const float* __restrict__ x, int64_t P, const float* __restrict__ d_out,
                                     HashGradLevels lv, int levels) {
     const int l = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = t >> 2;
     if (p >= P) return;
+    const int f = (int)t & 1, cx = ((int)t >> 1) & 1;
     const Cell c = locate(x, p, lv.res[l]);
-    const float2 g = *reinterpret_cast<const float2*>(d_out + p * (2 * levels) + 2 * l);
-    float* __restrict__ tab = lv.table[l];
+    const float g = d_out[p * (2 * levels) + 2 * l + f];
+    float* __restrict__ tab = lv.table[l] + f;
+    const unsigned size = lv.size[l];
+    const unsigned px = cx ? c.hi[0] : c.lo[0];
+    const float wx = cx ? c.w[0] : 1.0f - c.w[0];
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        const unsigned row = hash_row((corner & 4) ? c.hi[0] : c.lo[0], (corner & 2) ? c.hi[1] : c.lo[1],
-                                      (corner & 1) ? c.hi[2] : c.lo[2], lv.size[l]);
-        const float wgt = (((corner & 4) ? c.w[0] : 1.0f - c.w[0]) * ((corner & 2) ? c.w[1] : 1.0f - c.w[1])) *
-                          ((corner & 1) ? c.w[2] : 1.0f - c.w[2]);
-        atomicAdd(tab + 2 * (size_t)row + 0, wgt * g.x);
-        atomicAdd(tab + 2 * (size_t)row + 1, wgt * g.y);
+    for (int yz = 0; yz < 4; ++yz) {
+        const unsigned row = hash_row(px, (yz & 2) ? c.hi[1] : c.lo[1], (yz & 1) ? c.hi[2] : c.lo[2], size);
+        const float wgt = (wx * ((yz & 2) ? c.w[1] : 1.0f - c.w[1])) * ((yz & 1) ? c.w[2] : 1.0f - c.w[2]);
+        atomicAdd(tab + 2 * (size_t)row, wgt * g);
     }
 }
 
@@ -143,7 +150,7 @@ extern "C" int nerf_hashgrid_bwd(const float* x, int64_t P, const float* d_out, 
         NERF_REQUIRE(d_tables[l], "nerf_hashgrid_bwd: gradient table %d is null", l);
         lv.table[l] = d_tables[l];
     }
-    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)ceil_div(P, 256), levels), dim3(256), 0, (hipStream_t)stream, x,
-                       P, d_out, lv, levels);
+    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)ceil_div(4 * P, 256), levels), dim3(256), 0, (hipStream_t)stream,
+                       x, P, d_out, lv, levels);
     return check_launch("nerf_hashgrid_bwd");
 }

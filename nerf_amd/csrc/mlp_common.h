@@ -12,20 +12,9 @@
 // per step ("packed") so that the A operand of every MFMA is one coalesced
 // 256-byte read: pack[kt][r][lane][ot] = W[32*ot + (lane&31)][32*kt + rowmap(r, lane>>5)].
 #pragma once
-#include <type_traits>
 #include "common.h"
 
 namespace nerf {
-
-// Compile-time loop: f(std::integral_constant<int, I>) for I in [B, E), so that the
-// loop index can be used as a template argument.
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -52,71 +52,170 @@ __device__ __forceinline__ float stratified_depth(const float* __restrict__ z_li
     return lower + (upper - lower) * u[un];
 }
 
-// One thread per (ray, sample).  RAYGEN: derive the ray from the pixel instead of loading it.
+// Four consecutive (ray, sample) pairs per thread, 1024 per workgroup.  The few rays a
+// workgroup touches are derived (RAYGEN: from the pixel) or loaded once into LDS, the depths
+// go through LDS too, and the points leave as fully coalesced 16-byte stores (flat float f
+// of the workgroup's span is coordinate f%3 of sample f/3).
+constexpr int SMP_THREADS = 256, SMP_PER_THREAD = 4, SMP_BLOCK = SMP_THREADS * SMP_PER_THREAD;
 template <bool RAYGEN>
-__global__ void sample_kernel(const float* __restrict__ c2w, float fx, float fy, float cx, float cy, int W,
-                              const int32_t* __restrict__ pix, const float* __restrict__ in_o,
-                              const float* __restrict__ in_d, const float* __restrict__ z_lin,
-                              const float* __restrict__ u, int64_t R, int N, float* __restrict__ rays_o,
-                              float* __restrict__ rays_d, float* __restrict__ z_vals, float* __restrict__ pts) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= R * N) return;
-    const int64_t r = t / N;
-    const int n = (int)(t - r * N);
-    float o[3], d[3];
-    if (RAYGEN) {
-        pixel_ray(c2w, fx, fy, cx, cy, W, pix ? pix[r] : (int)r, o, d);
-        if (n == 0) {
+__global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __restrict__ c2w, float fx, float fy, float cx,
+                                                             float cy, int W, const int32_t* __restrict__ pix,
+                                                             const float* __restrict__ in_o, const float* __restrict__ in_d,
+                                                             const float* __restrict__ z_lin, const float* __restrict__ u,
+                                                             int64_t R, int N, float* __restrict__ rays_o,
+                                                             float* __restrict__ rays_d, float* __restrict__ z_vals,
+                                                             float* __restrict__ pts) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // depths, then (o, d) of the workgroup's rays
+    float* s_z = s_dyn;
+    float (*s_ray)[6] = reinterpret_cast<float (*)[6]>(s_dyn + SMP_BLOCK);
+    const int tid = threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * SMP_BLOCK, total = R * N;
+    const int64_t r_first = t0 / N;
+    const int n_first = (int)(t0 - r_first * N);                       // sample index of the block's first pair
+    const int here = (int)min((int64_t)SMP_BLOCK, total - t0);         // pairs in this workgroup
+    const int rays_here = (int)((t0 + here - 1) / N - r_first) + 1;    // <= SMP_BLOCK + 1
+    for (int k = tid; k < rays_here; k += SMP_THREADS) {
+        const int64_t r = r_first + k;
+        float o[3], d[3];
+        if (RAYGEN) {
+            pixel_ray(c2w, fx, fy, cx, cy, W, pix ? pix[r] : (int)r, o, d);
+            if (k > 0 || n_first == 0) {   // the workgroup that holds a ray's first sample publishes the ray
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (rays_o) rays_o[3 * r + k] = o[k];
-                if (rays_d) rays_d[3 * r + k] = d[k];
+                for (int c = 0; c < 3; ++c) {
+                    if (rays_o) rays_o[3 * r + c] = o[c];
+                    if (rays_d) rays_d[3 * r + c] = d[c];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o[c] = in_o[3 * r + c];
+                d[c] = in_d[3 * r + c];
             }
         }
-    } else {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            o[k] = in_o[3 * r + k];
-            d[k] = in_d[3 * r + k];
+        for (int c = 0; c < 3; ++c) {
+            s_ray[k][c] = o[c];
+            s_ray[k][3 + c] = d[c];
         }
     }
-    const float z = stratified_depth(z_lin, N, n, u, t);
-    if (z_vals) z_vals[t] = z;
-    if (pts) {
+    const int first = SMP_PER_THREAD * tid;
+    if (first + SMP_PER_THREAD <= here) {   // whole group of four: 16-byte accesses (t0 is a multiple of 1024)
+        float4 uu = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u) uu = *reinterpret_cast<const float4*>(u + t0 + first);
+        const float ua[4] = {uu.x, uu.y, uu.z, uu.w};
+        float zz[4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pts[3 * t + k] = o[k] + d[k] * z;  // src/Camera.py:140
+        for (int k = 0; k < 4; ++k) zz[k] = stratified_depth(z_lin, N, (n_first + first + k) % N, u ? ua : nullptr, k);
+        const float4 zv = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        if (z_vals) *reinterpret_cast<float4*>(z_vals + t0 + first) = zv;
+        *reinterpret_cast<float4*>(s_z + first) = zv;
+    } else {
+        for (int k = 0; k < SMP_PER_THREAD && first + k < here; ++k) {
+            const float zk = stratified_depth(z_lin, N, (n_first + first + k) % N, u, t0 + first + k);
+            if (z_vals) z_vals[t0 + first + k] = zk;
+            s_z[first + k] = zk;
+        }
+    }
+    if (!pts) return;
+    __syncthreads();
+    auto point_coord = [&](int f) {
+        const int smp = f / 3, c = f - 3 * smp;
+        const int k = (n_first + smp) / N;
+        return s_ray[k][c] + s_ray[k][3 + c] * s_z[smp];   // src/Camera.py:140
+    };
+    float* out = pts + t0 * 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int f = 4 * (j * SMP_THREADS + tid);
+        if (f + 4 <= 3 * here) {
+            *reinterpret_cast<float4*>(out + f) = make_float4(point_coord(f), point_coord(f + 1), point_coord(f + 2), point_coord(f + 3));
+        } else {
+            for (int k = 0; k < 4 && f + k < 3 * here; ++k) out[f + k] = point_coord(f + k);
+        }
     }
 }
 
+// LDS of a sample_kernel workgroup: 1024 depths and the rays its 1024 pairs can belong to.
+inline size_t sample_lds_bytes(int N) { return (SMP_BLOCK + (size_t)(SMP_BLOCK / N + 2) * 6) * sizeof(float); }
+
 // ---------------------------------------------------------------------------
-// Hierarchical sampling: one wavefront per ray, 4 rays per workgroup.
-// LDS per wave: cdf scan ping-pong (2*256), bins (256), merged depths (1024).
+// Hierarchical sampling: one wavefront per ray, 4 rays per workgroup; the waves
+// never meet (each works in its own LDS region, and LDS operations of one wave
+// complete in order).  Per ray: log-step scan of the 62 interior weights, a binary
+// search per fine sample, a bitonic sort of the fine depths in registers (EPL per
+// lane), and a merge with the already sorted coarse depths by rank: a coarse depth
+// moves up by the number of fine depths below it, a fine depth by the number of
+// coarse depths not above it.  Only values leave, so the order of equal depths is
+// immaterial.
 // ---------------------------------------------------------------------------
 constexpr int PDF_MAX_NC = 256;
 constexpr int PDF_MAX_ALL = 1024;
 constexpr int PDF_WAVES = 4;
 
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Value of lane ^ J.
+template <int J>
+__device__ __forceinline__ float xor_lane(float v) {
+    if constexpr (J == 1) return dpp_move<0xB1>(v, v);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return dpp_move<0x4E>(v, v);   // quad_perm [2,3,0,1]
+    else return __shfl_xor(v, J, 64);
+}
+
+// Ascending bitonic sort of 64*EPL values; element e = k*64 + lane lives in v[k] of the lane.
+template <int EPL>
+__device__ __forceinline__ void wave_bitonic_sort(float (&v)[EPL], int lane) {
+    static_for<1, 7 + (EPL == 1 ? 0 : EPL == 2 ? 1 : EPL == 4 ? 2 : EPL == 8 ? 3 : 4)>([&](auto cs) {
+        constexpr int SIZE = 1 << decltype(cs)::value;   // length of the sorted runs being formed
+        static_for<0, decltype(cs)::value>([&](auto cj) {
+            constexpr int J = SIZE >> (1 + decltype(cj)::value);   // partner distance
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                const int e = k * 64 + lane;
+                const bool asc = (e & SIZE) == 0 || SIZE == 64 * EPL;
+                if constexpr (J < 64) {
+                    const float o = xor_lane<J>(v[k]);
+                    const bool lower = (lane & J) == 0;
+                    v[k] = (lower == asc) ? fminf(v[k], o) : fmaxf(v[k], o);
+                } else {
+                    constexpr int KJ = J / 64;
+                    if ((k & KJ) == 0) {   // handle the pair (k, k + KJ) once
+                        const float lo = fminf(v[k], v[k ^ KJ]), hi = fmaxf(v[k], v[k ^ KJ]);
+                        v[k] = asc ? lo : hi;
+                        v[k ^ KJ] = asc ? hi : lo;
+                    }
+                }
+            }
+        });
+    });
+}
+
+template <int EPL>
 __global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z,
     const float* __restrict__ weights, const float* __restrict__ u, int64_t R, int Nc, int Nf,
     float* __restrict__ z_fine, int32_t* __restrict__ idx_out, float* __restrict__ z_all, float* __restrict__ pts) {
     __shared__ float s_scan[PDF_WAVES][2][PDF_MAX_NC];
     __shared__ float s_bins[PDF_WAVES][PDF_MAX_NC];
-    __shared__ float s_all[PDF_WAVES][PDF_MAX_ALL];
+    __shared__ float s_zc[PDF_WAVES][PDF_MAX_NC];
+    __shared__ float s_fine[PDF_WAVES][64 * EPL];
     __shared__ float s_sorted[PDF_WAVES][PDF_MAX_ALL];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t ray_raw = (int64_t)blockIdx.x * PDF_WAVES + wv;
-    const bool live = ray_raw < R;
-    const int64_t ray = live ? ray_raw : R - 1;  // idle waves shadow the last ray (barriers stay uniform)
+    const int64_t ray = (int64_t)blockIdx.x * PDF_WAVES + wv;
+    if (ray >= R) return;   // whole wave
     const float* zr = z + ray * Nc;
     const float* wr = weights + ray * Nc;
     const int nb = Nc - 1;  // bins and cdf entries
     const int nw = Nc - 2;  // interior weights
 
-    for (int k = lane; k < nb; k += 64) s_bins[wv][k] = 0.5f * (zr[k + 1] + zr[k]);
+    for (int k = lane; k < Nc; k += 64) s_zc[wv][k] = zr[k];
     for (int k = lane; k < nw; k += 64) s_scan[wv][0][k] = wr[k + 1] + 1e-5f;
-    for (int k = lane; k < Nc; k += 64) s_all[wv][k] = zr[k];
-    __syncthreads();
+    wave_lds_sync();
+    for (int k = lane; k < nb; k += 64) s_bins[wv][k] = 0.5f * (s_zc[wv][k + 1] + s_zc[wv][k]);
     // Log-step inclusive scan; the association order is part of the contract
     // (the CPU oracle performs the same additions).
     int cur = 0;
@@ -125,62 +224,80 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
             const float v = s_scan[wv][cur][k];
             s_scan[wv][cur ^ 1][k] = (k >= dd) ? v + s_scan[wv][cur][k - dd] : v;
         }
-        __syncthreads();
+        wave_lds_sync();
         cur ^= 1;
     }
     const float total = s_scan[wv][cur][nw - 1];
-    __syncthreads();
     // cdf[0] = 0, cdf[k+1] = c[k] / total, stored in the other half of the ping-pong
     float* cdf = s_scan[wv][cur ^ 1];
     for (int k = lane; k < nb; k += 64) cdf[k] = (k == 0) ? 0.0f : s_scan[wv][cur][k - 1] / total;
-    __syncthreads();
+    wave_lds_sync();
 
-    for (int f = lane; f < Nf; f += 64) {
-        const float uu = u[ray * Nf + f];
-        int lo = 0, hi = nb;  // first entry with cdf > uu
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
-        }
-        const int below = max(lo - 1, 0), above = min(lo, nb - 1);
-        const float c_lo = cdf[below], c_hi = cdf[above];
-        const float b_lo = s_bins[wv][below], b_hi = s_bins[wv][above];
-        float denom = c_hi - c_lo;
-        if (denom < 1e-5f) denom = 1.0f;
-        const float t = (uu - c_lo) / denom;
-        const float zf = b_lo + t * (b_hi - b_lo);
-        s_all[wv][Nc + f] = zf;
-        if (live) {
-            if (z_fine) z_fine[ray * Nf + f] = zf;
+    float zf[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int f = k * 64 + lane;
+        zf[k] = __builtin_inff();   // padding sorts to the end
+        if (f < Nf) {
+            const float uu = u[ray * Nf + f];
+            int lo = 0, hi = nb;  // first entry with cdf > uu
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+            }
+            const int below = max(lo - 1, 0), above = min(lo, nb - 1);
+            const float c_lo = cdf[below], c_hi = cdf[above];
+            const float b_lo = s_bins[wv][below], b_hi = s_bins[wv][above];
+            float denom = c_hi - c_lo;
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (uu - c_lo) / denom;
+            zf[k] = b_lo + t * (b_hi - b_lo);
+            if (z_fine) z_fine[ray * Nf + f] = zf[k];
             if (idx_out) idx_out[ray * Nf + f] = lo;
         }
     }
-    __syncthreads();
-    // Rank sort of the merged depths (ties broken by position: a stable sort).
+    wave_bitonic_sort<EPL>(zf, lane);
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) s_fine[wv][k * 64 + lane] = zf[k];
+    wave_lds_sync();
     const int na = Nc + Nf;
-    for (int i = lane; i < na; i += 64) {
-        const float v = s_all[wv][i];
-        int rank = 0;
-        for (int j = 0; j < na; ++j) {
-            const float w = s_all[wv][j];
-            rank += (w < v) || (w == v && j < i);
+    for (int i = lane; i < Nc; i += 64) {   // coarse depth i: fine depths strictly below it come first
+        const float v = s_zc[wv][i];
+        int lo = 0, hi = Nf;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_fine[wv][mid] < v) lo = mid + 1; else hi = mid;
         }
-        s_sorted[wv][rank] = v;
+        s_sorted[wv][i + lo] = v;
     }
-    __syncthreads();
-    if (!live) return;
-    float o[3], d[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        o[k] = rays_o[3 * ray + k];
-        d[k] = rays_d[3 * ray + k];
+    for (int k = 0; k < EPL; ++k) {         // fine depth e: coarse depths up to and including it come first
+        const int e = k * 64 + lane;
+        if (e < Nf) {
+            int lo = 0, hi = Nc;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_zc[wv][mid] <= zf[k]) lo = mid + 1; else hi = mid;
+            }
+            s_sorted[wv][e + lo] = zf[k];
+        }
     }
-    for (int i = lane; i < na; i += 64) {
-        const float v = s_sorted[wv][i];
-        if (z_all) z_all[ray * na + i] = v;
-        if (pts) {
+    wave_lds_sync();
+    if (z_all)
+        for (int i = lane; i < na; i += 64) z_all[ray * na + i] = s_sorted[wv][i];
+    if (pts) {
+        float o[3], d[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) pts[(ray * na + i) * 3 + k] = o[k] + d[k] * v;
+        for (int k = 0; k < 3; ++k) {
+            o[k] = rays_o[3 * ray + k];
+            d[k] = rays_d[3 * ray + k];
+        }
+        // flat float f of the ray's points is coordinate f%3 of sample f/3: coalesced stores
+        for (int f = lane; f < 3 * na; f += 64) {
+            const int smp = f / 3, c = f - 3 * smp;
+            const float oc = c == 0 ? o[0] : c == 1 ? o[1] : o[2];
+            const float dc = c == 0 ? d[0] : c == 1 ? d[1] : d[2];
+            pts[ray * na * 3 + f] = oc + dc * s_sorted[wv][smp];
         }
     }
 }
@@ -228,7 +345,8 @@ extern "C" int nerf_stratified_sample(const float* rays_o, const float* rays_d, 
     if (R == 0) return NERF_OK;
     NERF_REQUIRE(rays_o && rays_d && z_lin, "nerf_stratified_sample: null pointer");
     NERF_REQUIRE(R >= 0 && N >= 1, "nerf_stratified_sample: bad size R=%lld N=%d", (long long)R, N);
-    hipLaunchKernelGGL(sample_kernel<false>, dim3((unsigned)ceil_div(R * N, 256)), dim3(256), 0, (hipStream_t)stream,
+    NERF_REQUIRE(((size_t)u | (size_t)z_vals | (size_t)pts) % 16 == 0, "nerf_stratified_sample: u, z_vals and pts must be 16-byte aligned");
+    hipLaunchKernelGGL(sample_kernel<false>, dim3((unsigned)ceil_div(R * N, SMP_BLOCK)), dim3(SMP_THREADS), sample_lds_bytes(N), (hipStream_t)stream,
                        nullptr, 0.f, 0.f, 0.f, 0.f, 0, nullptr, rays_o, rays_d, z_lin, u, R, N, nullptr, nullptr,
                        z_vals, pts);
     return check_launch("nerf_stratified_sample");
@@ -242,7 +360,8 @@ extern "C" int nerf_raygen_sample(const float* c2w, float fx, float fy, float cx
     NERF_REQUIRE(H > 0 && W > 0 && R >= 0 && N >= 1, "nerf_raygen_sample: bad size");
     NERF_REQUIRE(pix || R == (int64_t)H * W, "nerf_raygen_sample: R must equal H*W when pix is NULL");
     NERF_REQUIRE((int64_t)H * W < (1ll << 31), "nerf_raygen_sample: image too large");
-    hipLaunchKernelGGL(sample_kernel<true>, dim3((unsigned)ceil_div(R * N, 256)), dim3(256), 0, (hipStream_t)stream, c2w,
+    NERF_REQUIRE(((size_t)u | (size_t)z_vals | (size_t)pts) % 16 == 0, "nerf_raygen_sample: u, z_vals and pts must be 16-byte aligned");
+    hipLaunchKernelGGL(sample_kernel<true>, dim3((unsigned)ceil_div(R * N, SMP_BLOCK)), dim3(SMP_THREADS), sample_lds_bytes(N), (hipStream_t)stream, c2w,
                        fx, fy, cx, cy, W, pix, nullptr, nullptr, z_lin, u, R, N, rays_o, rays_d, z_vals, pts);
     return check_launch("nerf_raygen_sample");
 }
@@ -255,8 +374,16 @@ extern "C" int nerf_pdf_sample(const float* rays_o, const float* rays_d, const f
     NERF_REQUIRE(Nc >= 3 && Nc <= PDF_MAX_NC, "nerf_pdf_sample: Nc=%d outside [3,%d]", Nc, PDF_MAX_NC);
     NERF_REQUIRE(Nf >= 1 && Nc + Nf <= PDF_MAX_ALL, "nerf_pdf_sample: Nc+Nf=%d exceeds %d", Nc + Nf, PDF_MAX_ALL);
     NERF_REQUIRE(R >= 0, "nerf_pdf_sample: R=%lld", (long long)R);
-    hipLaunchKernelGGL(pdf_sample_kernel, dim3((unsigned)ceil_div(R, PDF_WAVES)), dim3(PDF_WAVES * 64), 0,
-                       (hipStream_t)stream, rays_o, rays_d, z, weights, u, R, Nc, Nf, z_fine, idx, z_all, pts);
+    const dim3 grid((unsigned)ceil_div(R, PDF_WAVES)), block(PDF_WAVES * 64);
+#define PDF_LAUNCH(EPL)                                                                                              \
+    hipLaunchKernelGGL(pdf_sample_kernel<EPL>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d, z, weights, u, R, \
+                       Nc, Nf, z_fine, idx, z_all, pts)
+    if (Nf <= 64) PDF_LAUNCH(1);
+    else if (Nf <= 128) PDF_LAUNCH(2);
+    else if (Nf <= 256) PDF_LAUNCH(4);
+    else if (Nf <= 512) PDF_LAUNCH(8);
+    else PDF_LAUNCH(16);
+#undef PDF_LAUNCH
     return check_launch("nerf_pdf_sample");
 }
 
