@@ -138,19 +138,22 @@ extern "C" int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* 
     return check_launch("nerf_hashgrid_fwd");
 }
 
+int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, const int* res, const int* sizes,
+                                  int levels, float* const* d_tables, hipStream_t stream) {
+    HashGradLevels lv;
+    if (int rc = fill_levels(res, sizes, levels, lv.res, lv.size)) return rc;
+    for (int l = 0; l < levels; ++l) lv.table[l] = d_tables[l];
+    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)ceil_div(4 * P, 256), levels), dim3(256), 0, stream, x, P, d_enc,
+                       lv, levels);
+    return check_launch("hashgrid_scatter");
+}
+
 extern "C" int nerf_hashgrid_bwd(const float* x, int64_t P, const float* d_out, const int* res, const int* sizes,
                                  int levels, float* const* d_tables, void* stream) {
     if (P == 0) return NERF_OK;
     NERF_REQUIRE(x && d_out && res && sizes && d_tables, "nerf_hashgrid_bwd: null pointer");
     NERF_REQUIRE(levels >= 1 && levels <= HG_MAX_LEVELS, "nerf_hashgrid_bwd: levels=%d outside [1,%d]", levels, HG_MAX_LEVELS);
     NERF_REQUIRE(P >= 0, "nerf_hashgrid_bwd: P=%lld", (long long)P);
-    HashGradLevels lv;
-    if (int rc = fill_levels(res, sizes, levels, lv.res, lv.size)) return rc;
-    for (int l = 0; l < levels; ++l) {
-        NERF_REQUIRE(d_tables[l], "nerf_hashgrid_bwd: gradient table %d is null", l);
-        lv.table[l] = d_tables[l];
-    }
-    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)ceil_div(4 * P, 256), levels), dim3(256), 0, (hipStream_t)stream,
-                       x, P, d_out, lv, levels);
-    return check_launch("nerf_hashgrid_bwd");
+    for (int l = 0; l < levels; ++l) NERF_REQUIRE(d_tables[l], "nerf_hashgrid_bwd: gradient table %d is null", l);
+    return launch_hashgrid_scatter(x, P, d_out, res, sizes, levels, d_tables, (hipStream_t)stream);
 }

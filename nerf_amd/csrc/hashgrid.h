@@ -81,4 +81,9 @@ __device__ __forceinline__ float corner_weight(const Cell& c, int corner) {
            ((corner & 1) ? c.w[2] : 1.0f - c.w[2]);
 }
 
+// d_tables[l][row][f] += corner weight * d_enc[p][2l + f] over all points and corners
+// (the backward of the hash-grid gather); defined with the encoder kernels.
+int launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, const int* res, const int* sizes, int levels,
+                            float* const* d_tables, hipStream_t stream);
+
 }  // namespace nerf

@@ -41,7 +41,8 @@ constexpr int DYC = 0;      // [P32][64]
 constexpr int DRAW = 64;    // [P32][32]
 constexpr int DYD = 96;     // [P32][64]
 constexpr int DOUT4 = 160;  // [P32][4]
-constexpr int PER_POINT2 = 164;
+constexpr int DENC = 164;   // [P32][32] gradient of the encoding, natural feature order
+constexpr int PER_POINT2 = 196;
 }  // namespace nw
 
 struct NgpLevels {
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void ngp_fwd_kernel(const float* __restrict__ 
 // Backward-data chain ending in the hash-table scatter.
 __global__ __launch_bounds__(256) void ngp_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ d_rgb,
                                                            const float* __restrict__ d_sigma, long long P,
-                                                           NgpGradLevels lv, const float* __restrict__ pk,
+                                                           const float* __restrict__ pk,
                                                            const float* __restrict__ rgb,
                                                            const float* __restrict__ sigma,
                                                            const float* __restrict__ ws, float* __restrict__ ws2) {
@@ -227,22 +228,11 @@ __global__ __launch_bounds__(256) void ngp_bwd_data_kernel(const float* __restri
     f32x16 de[1];
     zero_tiles<1>(de);
     dense<2, 1>(pk + np::B_D1, dyd, de, lane);   // register r = d feature (16h + r): this lane's own levels
-    if (!ix.valid) return;
+    // The table gradients are scattered by a second launch that lays lanes out for shared
+    // cache lines (launch_hashgrid_scatter); this lane holds d feature 16h + r in register r.
+    float4* denc = reinterpret_cast<float4*>(ws2 + ix.P32 * nw::DENC + ix.gp * 32 + 16 * h);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int res = h ? lv.res[8 + j] : lv.res[j];
-        const unsigned size = h ? lv.size[8 + j] : lv.size[j];
-        float* __restrict__ tab = h ? lv.table[8 + j] : lv.table[j];
-        const Cell c = locate(x, ix.lp, res);
-        const float gx = de[0][2 * j], gy = de[0][2 * j + 1];
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const unsigned row = corner_row(c, corner, size);
-            const float wgt = corner_weight(c, corner);
-            atomicAdd(tab + 2 * (size_t)row, wgt * gx);
-            atomicAdd(tab + 2 * (size_t)row + 1, wgt * gy);
-        }
-    }
+    for (int q = 0; q < 4; ++q) denc[q] = make_float4(de[0][4 * q], de[0][4 * q + 1], de[0][4 * q + 2], de[0][4 * q + 3]);
 }
 
 }  // namespace nerf
@@ -331,16 +321,10 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
                  "nerf_mlp_ngp_bwd: null pointer");
     for (int i = 0; i < NERF_NGP_NPARAM; ++i) NERF_REQUIRE(grads[i], "nerf_mlp_ngp_bwd: gradient %d is null", i);
     if (int rc = check_levels(res, sizes, "nerf_mlp_ngp_bwd")) return rc;
-    NgpGradLevels lv;
-    for (int l = 0; l < 16; ++l) {
-        NERF_REQUIRE(d_tables[l], "nerf_mlp_ngp_bwd: gradient table %d is null", l);
-        lv.table[l] = d_tables[l];
-        lv.res[l] = res[l];
-        lv.size[l] = (unsigned)sizes[l];
-    }
+    for (int l = 0; l < 16; ++l) NERF_REQUIRE(d_tables[l], "nerf_mlp_ngp_bwd: gradient table %d is null", l);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ngp_bwd_data_kernel, dim3((unsigned)ceil_div(P, 128)), dim3(256), 0, st, x, d_rgb, d_sigma,
-                       (long long)P, lv, packed, rgb, sigma, ws, ws2);
+                       (long long)P, packed, rgb, sigma, ws, ws2);
     if (int rc = check_launch("nerf_mlp_ngp_bwd(data)")) return rc;
 
     const long long P32 = (P + 31) / 32 * 32;
@@ -366,6 +350,7 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
         p.k_first = 1;
         parts.part[n++] = p;
     }
+    if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, res, sizes, 16, d_tables, st)) return rc;
     parts.n = n;
     if (int rc = launch_wgrad(parts, P32, st)) return rc;
     SkinnyPart c2{DOUT4, HC, grads[6], grads[7], 4, 64, 1, 3, 64};                                           // fc_color.2
