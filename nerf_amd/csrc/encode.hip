@@ -9,24 +9,45 @@ namespace nerf {
 
 // ------------------------------------------------------------------ PE ----
 // out[p][0:D] = x; out[p][D + 2*D*f + D*s + c] = (s ? cos : sin)(2^f * x[p][c])
-// (src/utils/positional_encoding.py:30-36).  One thread per output element so
-// that the [P, D(2L+1)] rows are written fully coalesced.
-__global__ void encode_pe_kernel(const float* __restrict__ x, int64_t P, int D, int L, float* __restrict__ out) {
+// (src/utils/positional_encoding.py:30-36).  One thread per (point, coordinate) computes
+// the whole column family of its coordinate (sincos_octaves; bands 20 and up, where angle
+// doubling in double has lost too many bits, by library calls), the workgroup's rows are
+// assembled in LDS and leave fully coalesced.
+constexpr int PE_THREADS = 256;
+constexpr int PE_CHAIN = 20;
+template <int LC>   // bands computed by the octave recurrence = min(L, LC)
+__global__ __launch_bounds__(PE_THREADS) void encode_pe_kernel(const float* __restrict__ x, int64_t P, int D, int L,
+                                                               float* __restrict__ out) {
+    extern __shared__ float s_rows[];   // [points per workgroup][width]
     const int width = D * (2 * L + 1);
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P * width) return;
-    const int64_t p = t / width;
-    const int col = (int)(t - p * width);
-    if (col < D) {
-        out[t] = x[p * D + col];
-        return;
+    const int ppb = PE_THREADS / D;                    // points per workgroup
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int here = (int)min((int64_t)ppb, P - p0);
+    const int tid = threadIdx.x;
+    if (tid < here * D) {
+        const int pl = tid / D, c = tid - pl * D;
+        const float xv = x[p0 * D + tid];
+        float* row = s_rows + pl * width;
+        row[c] = xv;
+        float sn[LC], cs[LC];
+        sincos_octaves<LC>(xv, sn, cs);
+#pragma unroll
+        for (int f = 0; f < LC; ++f) {
+            if (f < L) {
+                row[D + 2 * D * f + c] = sn[f];
+                row[D + 2 * D * f + D + c] = cs[f];
+            }
+        }
+        for (int f = LC; f < L; ++f) {
+            const float arg = ldexpf(xv, f);  // 2^f * x, exact like the reference's fp32 product
+            row[D + 2 * D * f + c] = sinf(arg);
+            row[D + 2 * D * f + D + c] = cosf(arg);
+        }
     }
-    const int q = col - D;
-    const int f = q / (2 * D);
-    const int r = q - f * 2 * D;
-    const int s = r / D, c = r - s * D;
-    const float arg = ldexpf(x[p * D + c], f);  // 2^f * x, exact like the reference's fp32 product
-    out[t] = s ? cosf(arg) : sinf(arg);
+    __syncthreads();
+    const int n = here * width;
+    float* dst = out + p0 * width;
+    for (int i = tid; i < n; i += PE_THREADS) dst[i] = s_rows[i];
 }
 
 // ----------------------------------------------------------- hash grid ----
@@ -105,9 +126,13 @@ extern "C" int nerf_encode_pe(const float* x, int64_t P, int D, int L, float* ou
     if (P == 0) return NERF_OK;
     NERF_REQUIRE(x && out, "nerf_encode_pe: null pointer");
     NERF_REQUIRE(P >= 0 && D >= 1 && L >= 0 && L <= 32, "nerf_encode_pe: bad size P=%lld D=%d L=%d", (long long)P, D, L);
-    const int64_t n = P * D * (2 * L + 1);
-    hipLaunchKernelGGL(encode_pe_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, P, D, L,
-                       out);
+    NERF_REQUIRE(D <= PE_THREADS, "nerf_encode_pe: D=%d exceeds %d", D, PE_THREADS);
+    const int ppb = PE_THREADS / D;
+    const size_t lds = (size_t)ppb * D * (2 * L + 1) * sizeof(float);   // <= 256 * 65 floats
+    const dim3 grid((unsigned)ceil_div(P, ppb)), block(PE_THREADS);
+    if (L <= 4) hipLaunchKernelGGL(encode_pe_kernel<4>, grid, block, lds, (hipStream_t)stream, x, P, D, L, out);
+    else if (L <= 10) hipLaunchKernelGGL(encode_pe_kernel<10>, grid, block, lds, (hipStream_t)stream, x, P, D, L, out);
+    else hipLaunchKernelGGL(encode_pe_kernel<PE_CHAIN>, grid, block, lds, (hipStream_t)stream, x, P, D, L, out);
     return check_launch("nerf_encode_pe");
 }
 

@@ -412,33 +412,32 @@ __device__ __forceinline__ void apply_bits(f32x16 (&a)[NT], uint4 bits) {
         }
 }
 
-// Element e of the positional encoding of a 3-vector with L frequency bands:
-// [x, sin(2^0 x), cos(2^0 x), ...] (src/utils/positional_encoding.py:30-36); 0 beyond the end.
-__device__ __forceinline__ float pe_element(float x0, float x1, float x2, int e, int L) {
-    if (e >= 3 * (2 * L + 1)) return 0.0f;
-    int c, f = 0, s = -1;
-    if (e < 3) {
-        c = e;
-    } else {
-        const int q = e - 3;
-        f = q / 6;
-        const int rr = q - 6 * f;
-        s = rr >= 3;
-        c = rr - 3 * s;
+// Positional encoding of a 3-vector with L frequency bands as register tiles: element e of
+// [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...] (each block 3 wide; 0 beyond the end) sits in
+// tile e/32, register r, lane half h with e%32 = rowmap(r, h).
+template <int NT, int L>
+__device__ __forceinline__ void pe_tiles(f32x16 (&out)[NT], float x0, float x1, float x2, int h) {
+    constexpr int WIDTH = 3 * (2 * L + 1);
+    float val[32 * NT + 4];
+    {
+        float sn[3][L], cs[3][L];
+        sincos_octaves<L>(x0, sn[0], cs[0]);
+        sincos_octaves<L>(x1, sn[1], cs[1]);
+        sincos_octaves<L>(x2, sn[2], cs[2]);
+#pragma unroll
+        for (int e = 0; e < 32 * NT + 4; ++e) {
+            if (e >= WIDTH) val[e] = 0.0f;
+            else if (e < 3) val[e] = e == 0 ? x0 : e == 1 ? x1 : x2;
+            else {
+                const int q = e - 3, f = q / 6, rr = q % 6;
+                val[e] = rr >= 3 ? cs[rr - 3][f < L ? f : 0] : sn[rr][f < L ? f : 0];
+            }
+        }
     }
-    const float xc = c == 0 ? x0 : (c == 1 ? x1 : x2);
-    if (s < 0) return xc;
-    const float arg = ldexpf(xc, f);
-    return s ? cosf(arg) : sinf(arg);
-}
-
-// Encoded tile(s) in the register layout: tile t, register r = element 32t + rowmap(r,h).
-template <int NT>
-__device__ __forceinline__ void pe_tiles(f32x16 (&out)[NT], float x0, float x1, float x2, int L, int h) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[t][r] = pe_element(x0, x1, x2, 32 * t + rowmap(r, 0) + 4 * h, L);
+        for (int r = 0; r < 16; ++r) out[t][r] = h ? val[32 * t + rowmap(r, 0) + 4] : val[32 * t + rowmap(r, 0)];
 }
 
 __device__ __forceinline__ float softplus_f(float x) {  // F.softplus, beta 1, threshold 20

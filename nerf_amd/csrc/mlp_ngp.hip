@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void ngp_fwd_kernel(const float* __restrict__ 
             float d0 = dirs[3 * dr], d1 = dirs[3 * dr + 1], d2 = dirs[3 * dr + 2];
             const float n = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
             d0 /= n; d1 /= n; d2 /= n;
-            pe_tiles<1>(de, d0, d1, d2, 4, h);
+            pe_tiles<1, 4>(de, d0, d1, d2, h);
         } else {
             zero_tiles<1>(de);
         }

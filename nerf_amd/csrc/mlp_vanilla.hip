@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     uint4* mask_out = SAVE ? reinterpret_cast<uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane : nullptr;
 
     f32x16 xe[2];
-    pe_tiles<2>(xe, x0, x1, x2, 10, h);
+    pe_tiles<2, 10>(xe, x0, x1, x2, h);
     ws_ready();
 
     f32x16 hc[8], acc[8];
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
     const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
-    pe_tiles<1>(de, dirs[3 * dr], dirs[3 * dr + 1], dirs[3 * dr + 2], 4, h);
+    pe_tiles<1, 4>(de, dirs[3 * dr], dirs[3 * dr + 1], dirs[3 * dr + 2], h);
     f32x16 hr[4];
     fill_rows<4>(hr, pk + vp::S_B1, h);
     dense_shared<8, 4, SAVE>(wst, pk + vp::F_RGB0F, NextChunks{pk + vp::F_RGB0D, 4, nullptr, 0}, acc, hr, rows_of(vw::FEAT));

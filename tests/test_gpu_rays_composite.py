@@ -73,7 +73,27 @@ def test_raygen_sample_fused_equals_two_step(dev):
     assert torch.equal(z.cpu(), z_o) and torch.equal(pts.cpu(), pts_o)
 
 
-@pytest.mark.parametrize("Nc,Nf", [(64, 128), (17, 5), (3, 1), (100, 200), (256, 768)])
+@pytest.mark.parametrize("R,N", [(1000, 37), (7, 3), (3000, 1), (513, 130), (5, 1500)])
+def test_raygen_sample_ragged_sizes(dev, R, N):
+    """Workgroups of 1024 (ray, sample) pairs that start and end mid-ray, rays longer than a workgroup."""
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(R + N)
+    H, W = 60, 50
+    c2w = O.look_at_camera(torch.tensor([1.0, 1.0, 2.0]), torch.zeros(3), torch.tensor([0.0, 0.0, 1.0])).to(dev)
+    pix = torch.randint(0, H * W, (R,), generator=gen, dtype=torch.int32).to(dev)
+    u = torch.rand(R, N, generator=gen).to(dev)
+    z_lin = torch.linspace(0.5, 3.0, N).to(dev)
+    o, d, z, pts = ops.raygen_sample(c2w, 55.0, 55.0, 25.0, 30.0, H, W, pix, z_lin, u)
+    o2, d2 = ops.raygen(c2w, 55.0, 55.0, 25.0, 30.0, H, W, pix)
+    assert torch.equal(o, o2) and torch.equal(d, d2)
+    pts_o, z_o = O.sample_points_along_rays(o.cpu(), d.cpu(), 0.5, 3.0, N, u.cpu())
+    assert torch.equal(z.cpu(), z_o) and torch.equal(pts.cpu(), pts_o)
+    z3, pts3 = ops.stratified_sample(o2, d2, z_lin, None)     # unperturbed
+    pts_n, z_n = O.sample_points_along_rays(o.cpu(), d.cpu(), 0.5, 3.0, N, None)
+    assert torch.equal(z3.cpu(), z_n.expand_as(z3.cpu())) and torch.equal(pts3.cpu(), pts_n)
+
+
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (17, 5), (3, 1), (100, 200), (64, 400), (256, 768)])
 def test_pdf_sample_indices_bit_exact(dev, Nc, Nf):
     from nerf_amd import ops
     gen = torch.Generator().manual_seed(100 + Nc)
