@@ -71,6 +71,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (lane_value(v, 15) + lane_value(v, 31)) + (lane_value(v, 47) + lane_value(v, 63));
 }
 
+// K consecutive floats as one load (dword, x2, x3 or x4 pieces; 4-byte aligned).
+template <int K>
+struct __attribute__((packed, aligned(4))) FloatRun {
+    float v[K];
+};
+
 // sin and cos of 2^k x for k = 0..L-1 (x a float, the products 2^k x exact as in the
 // reference, src/utils/positional_encoding.py:30-36), correctly rounded to float up to
 // ~1e-9: one sin/cos pair in double (quadrant reduction, Taylor polynomials on

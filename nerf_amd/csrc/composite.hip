@@ -38,12 +38,6 @@ __device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
     return dpp_move<DPP_WAVE_SHL1>(0.0f, v);
 }
 
-// K consecutive floats as one load (dword, x2, x3 or x4 pieces; 4-byte aligned).
-template <int K>
-struct __attribute__((packed, aligned(4))) FloatRun {
-    float v[K];
-};
-
 // A lane's IPL consecutive samples of one ray: loads, then alpha, t = 1-alpha+1e-10, T and w.
 // FULL: N == 64*IPL, every lane is full and the loads are unconditional vector loads.
 template <int IPL, bool FULL>

@@ -99,15 +99,15 @@ __global__ void hashgrid_fwd_kernel(const float* __restrict__ x, int64_t P, Hash
 // travel in one instruction and, unless the row wraps, in one line.
 __global__ void hashgrid_bwd_kernel(const float* __restrict__ x, int64_t P, const float* __restrict__ d_out,
                                     HashGradLevels lv, int levels) {
-    const int l = blockIdx.y;
+    const int j = blockIdx.y, l = lv.id[j];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t >> 2;
     if (p >= P) return;
     const int f = (int)t & 1, cx = ((int)t >> 1) & 1;
-    const Cell c = locate(x, p, lv.res[l]);
+    const Cell c = locate(x, p, lv.res[j]);
     const float g = d_out[p * (2 * levels) + 2 * l + f];
-    float* __restrict__ tab = lv.table[l] + f;
-    const unsigned size = lv.size[l];
+    float* __restrict__ tab = lv.table[j] + f;
+    const unsigned size = lv.size[j];
     const unsigned px = cx ? c.hi[0] : c.lo[0];
     const float wx = cx ? c.w[0] : 1.0f - c.w[0];
 #pragma unroll
@@ -115,6 +115,41 @@ __global__ void hashgrid_bwd_kernel(const float* __restrict__ x, int64_t P, cons
         const unsigned row = hash_row(px, (yz & 2) ? c.hi[1] : c.lo[1], (yz & 1) ? c.hi[2] : c.lo[2], size);
         const float wgt = (wx * ((yz & 2) ? c.w[1] : 1.0f - c.w[1])) * ((yz & 1) ? c.w[2] : 1.0f - c.w[2]);
         atomicAdd(tab + 2 * (size_t)row, wgt * g);
+    }
+}
+
+// The same for a level whose whole gradient table fits in LDS (the coarsest levels): each
+// workgroup adds its share of the points into an LDS copy and then adds the copy to the
+// table once, contiguously (contiguous atomics run ~16 times faster than scattered ones).
+constexpr int HG_LDS_THREADS = 1024;
+constexpr unsigned HG_LDS_MAX_ROWS = 16384;   // 128 KiB of LDS
+__global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const float* __restrict__ x, int64_t P,
+                                                                          const float* __restrict__ d_out, float* tab,
+                                                                          int res, unsigned size, int l, int levels) {
+    extern __shared__ float s_tab[];   // [size][2]
+    const int tid = threadIdx.x;
+    for (unsigned i = tid; i < 2 * size; i += HG_LDS_THREADS) s_tab[i] = 0.0f;
+    __syncthreads();
+    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+    const int64_t p_begin = per * blockIdx.x, p_end = min(P, p_begin + per);
+    for (int64_t t = 4 * p_begin + tid; t < 4 * p_end; t += HG_LDS_THREADS) {
+        const int64_t p = t >> 2;
+        const int f = (int)t & 1, cx = ((int)t >> 1) & 1;
+        const Cell c = locate(x, p, res);
+        const float g = d_out[p * (2 * levels) + 2 * l + f];
+        const unsigned px = cx ? c.hi[0] : c.lo[0];
+        const float wx = cx ? c.w[0] : 1.0f - c.w[0];
+#pragma unroll
+        for (int yz = 0; yz < 4; ++yz) {
+            const unsigned row = hash_row(px, (yz & 2) ? c.hi[1] : c.lo[1], (yz & 1) ? c.hi[2] : c.lo[2], size);
+            const float wgt = (wx * ((yz & 2) ? c.w[1] : 1.0f - c.w[1])) * ((yz & 1) ? c.w[2] : 1.0f - c.w[2]);
+            atomicAdd(s_tab + 2 * row + f, wgt * g);
+        }
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < 2 * size; i += HG_LDS_THREADS) {
+        const float v = s_tab[i];
+        if (v != 0.0f) atomicAdd(tab + i, v);
     }
 }
 
@@ -165,11 +200,34 @@ extern "C" int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* 
 
 int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, const int* res, const int* sizes,
                                   int levels, float* const* d_tables, hipStream_t stream) {
+    static bool lds_enabled = false;   // idempotent: the attribute belongs to the kernel, not to a call
+    if (!lds_enabled) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(hashgrid_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(HG_LDS_MAX_ROWS * 2 * sizeof(float))) != hipSuccess)
+            return fail(NERF_ELAUNCH, "hashgrid_scatter: cannot raise the LDS limit");
+        lds_enabled = true;
+    }
     HashGradLevels lv;
-    if (int rc = fill_levels(res, sizes, levels, lv.res, lv.size)) return rc;
-    for (int l = 0; l < levels; ++l) lv.table[l] = d_tables[l];
-    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)ceil_div(4 * P, 256), levels), dim3(256), 0, stream, x, P, d_enc,
-                       lv, levels);
+    int big = 0;
+    for (int l = 0; l < levels; ++l) {
+        if (res[l] < 1 || sizes[l] < 1) return fail(NERF_EINVAL, "hashgrid: level %d has res=%d size=%d", l, res[l], sizes[l]);
+        if ((unsigned)sizes[l] <= HG_LDS_MAX_ROWS && P >= 4096) {
+            // enough points per workgroup to pay for adding the whole table once per workgroup
+            const int blocks = (int)(P / 4096 < 256 ? P / 4096 : 256);
+            hipLaunchKernelGGL(hashgrid_bwd_lds_kernel, dim3(blocks), dim3(HG_LDS_THREADS), (size_t)sizes[l] * 2 * sizeof(float),
+                               stream, x, P, d_enc, d_tables[l], res[l], (unsigned)sizes[l], l, levels);
+            if (int rc = check_launch("hashgrid_scatter(lds)")) return rc;
+        } else {
+            lv.table[big] = d_tables[l];
+            lv.res[big] = res[l];
+            lv.size[big] = (unsigned)sizes[l];
+            lv.id[big] = l;
+            ++big;
+        }
+    }
+    if (big == 0) return NERF_OK;
+    hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)ceil_div(4 * P, 256), big), dim3(256), 0, stream, x, P, d_enc, lv,
+                       levels);
     return check_launch("hashgrid_scatter");
 }
 

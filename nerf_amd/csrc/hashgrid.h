@@ -12,10 +12,11 @@ struct HashLevels {
     int res[HG_MAX_LEVELS];
     unsigned size[HG_MAX_LEVELS];
 };
-struct HashGradLevels {
+struct HashGradLevels {   // a subset of the levels; id = position of the level in the encoding
     float* table[HG_MAX_LEVELS];
     int res[HG_MAX_LEVELS];
     unsigned size[HG_MAX_LEVELS];
+    int id[HG_MAX_LEVELS];
 };
 
 // Floor-modulo of a possibly negative cell coordinate (Python's % on int64,
