@@ -46,13 +46,15 @@ int nerf_raygen(const float* c2w, float fx, float fy, float cx, float cy, int H,
  * depths (torch.linspace(near, far, N), computed by the caller so that the
  * values are the reference's bit for bit).  u: [R,N] uniforms in [0,1) that the
  * reference would draw with torch.rand_like, or NULL for perturb=False.
- * Outputs z_vals [R,N] and pts [R,N,3] (either may be NULL). */
+ * Outputs z_vals [R,N] and pts [R,N,3] (either may be NULL).  u, z_vals and pts
+ * must be 16-byte aligned (they are accessed 16 bytes at a time). */
 int nerf_stratified_sample(const float* rays_o, const float* rays_d, const float* z_lin,
                            const float* u, int64_t R, int N, float* z_vals, float* pts,
                            void* stream);
 
 /* Fused form of the two calls above: rays are generated and sampled without a
- * round trip through memory.  Any of rays_o/rays_d/z_vals/pts may be NULL. */
+ * round trip through memory.  Any of rays_o/rays_d/z_vals/pts may be NULL; the
+ * alignment rule of nerf_stratified_sample applies. */
 int nerf_raygen_sample(const float* c2w, float fx, float fy, float cx, float cy, int H, int W,
                        const int32_t* pix, int64_t R, const float* z_lin, const float* u, int N,
                        float* rays_o, float* rays_d, float* z_vals, float* pts, void* stream);
