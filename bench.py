@@ -55,10 +55,14 @@ def make_batch(rank: int, rays: int, dev):
     return lego_pose(0).to(dev), pix.to(dev), u_c.to(dev), u_f.to(dev), gt.to(dev)
 
 
+NGP_NEAR, NGP_FAR = 0.05, 1.2   # src/train_nerf_ngp.py:32-33 (unit-sphere-normalised poses)
+
+
 def gpu_main(args):
     import torch.distributed as dist
     from nerf_amd import ops
     from nerf_amd.models.NeRF import NeRF
+    from nerf_amd.optim import FusedAdam
     from nerf_amd.render import nerf_loss, render_rays
     from nerf_amd.dist import GradAverager
 
@@ -69,26 +73,48 @@ def gpu_main(args):
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    torch.manual_seed(0)
-    coarse = NeRF().to(dev)
-    torch.manual_seed(1)
-    fine = NeRF().to(dev)
-    params = list(coarse.parameters()) + list(fine.parameters())
-    opt = torch.optim.Adam(params, lr=5e-4)
-    averager = GradAverager(params) if world > 1 else None
     c2w, pix, u_c, u_f, gt = make_batch(rank, args.rays, dev)
+    if args.model == "ngp":
+        # the hash-grid variant: 64 samples, one model, the weight regulariser of
+        # src/train_nerf_ngp.py:221-222 and its optimiser settings (:55); camera on the unit sphere
+        from nerf_amd.models.FastNGPNeRF import FastNGPNeRF
+        torch.manual_seed(0)
+        coarse = FastNGPNeRF().to(dev)
+        params = list(coarse.parameters())
+        opt = FusedAdam(params, lr=1e-2, eps=1e-15)
+        c2w = c2w.clone()
+        c2w[:, 3] = c2w[:, 3] / 4.03
 
-    def step():
-        o, d = ops.raygen(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix)
-        out = render_rays(coarse, o, d, NEAR, FAR, N_COARSE, perturb=True, t_rand=u_c, white_bkgd=True,
-                          fine_model=fine, n_importance=N_FINE, u_fine=u_f)
-        loss = nerf_loss(out, gt)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        if averager is not None:
-            averager.average()
-        opt.step()
-        return loss
+        def step():
+            o, d = ops.raygen(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix)
+            out = render_rays(coarse, o, d, NGP_NEAR, NGP_FAR, N_COARSE, perturb=True, t_rand=u_c, white_bkgd=False)
+            loss = torch.nn.functional.mse_loss(out["rgb"], gt) + 0.05 * (1.0 - out["weights"].sum(dim=-1)).abs().mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            if averager is not None:
+                averager.average()
+            opt.step()
+            return loss
+    else:
+        torch.manual_seed(0)
+        coarse = NeRF().to(dev)
+        torch.manual_seed(1)
+        fine = NeRF().to(dev)
+        params = list(coarse.parameters()) + list(fine.parameters())
+        opt = FusedAdam(params, lr=5e-4)   # torch.optim.Adam's update in one launch (tests/test_gpu_optim.py)
+
+        def step():
+            o, d = ops.raygen(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix)
+            out = render_rays(coarse, o, d, NEAR, FAR, N_COARSE, perturb=True, t_rand=u_c, white_bkgd=True,
+                              fine_model=fine, n_importance=N_FINE, u_fine=u_f)
+            loss = nerf_loss(out, gt)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            if averager is not None:
+                averager.average()
+            opt.step()
+            return loss
+    averager = GradAverager(params) if world > 1 else None
 
     def fence():
         torch.cuda.synchronize()
@@ -108,10 +134,22 @@ def gpu_main(args):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     result = None
-    if rank == 0:
+    if rank == 0 and args.model == "ngp":
+        result = {
+            "metric": "rays/sec fwd+bwd (hash-grid model, 64 samples)", "value": world * args.rays * args.steps / dt,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Instant-NGP variant (16 levels, 2^19 rows, 64-wide MLPs), 800x800 camera on the unit "
+                                   "sphere, 64 samples, %d-ray batch per GPU, one training step incl. Adam over the "
+                                   "tables" % args.rays,
+                       "rays_per_gpu": args.rays, "parallelism": "ray-sharded dp%d" % world, "final_loss": final_loss},
+            "roofline": ngp_roofline(coarse, args.rays, dev),
+        }
+    elif rank == 0:
         roof = kernel_roofline(coarse, args.rays, dev)
         result = {
             "metric": "rays/sec fwd+bwd (lego 800x800, 64 coarse + 128 fine)",
@@ -203,6 +241,26 @@ def kernel_roofline(model, rays, dev):
             "all_kernels_ms": {k: v[0] * 1e3 for k, v in kernels.items()}}
 
 
+def ngp_roofline(model, rays, dev):
+    """The table-gradient scatter is what the hash-grid step spends most of its time in: algorithmic
+    bytes (1,024 B of float atomics per point) over its HIP-event time, against the HBM peak."""
+    from nerf_amd import _lib as L
+    P = rays * N_COARSE
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(P, 3, generator=g) * 2 - 1).to(dev)
+    d_enc = torch.randn(P, 32, generator=g).to(dev)
+    tabs = [e.weight.detach() for e in model.hash_encoder.embeddings]
+    grads = [torch.zeros_like(t) for t in tabs]
+    res = L.int_array(model.hash_encoder.resolutions)
+    sizes = L.int_array([int(t.shape[0]) for t in tabs])
+    ptrs = L.ptr_array(grads)
+    t = _time_kernel(lambda: L.check(L.lib().nerf_hashgrid_bwd(L.ptr(x), P, L.ptr(d_enc), res, sizes, 16, ptrs,
+                                                               L.stream_of(x)), "hashgrid_bwd"))
+    achieved = 1024.0 * P / t / 1e9
+    return {"bound": "hbm", "kernel": "hashgrid_bwd_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "frac": achieved / 8000.0, "traffic": None, "points_per_launch": P}
+
+
 def cpu_baseline(rays):
     """The reference's op sequence (CPU PyTorch restatement in oracle/) on the host
     cores: same camera, same sampling, two 8x256 MLPs evaluated in 2048-point
@@ -250,6 +308,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--model", choices=["vanilla", "ngp"], default="vanilla",
+                    help="vanilla = the headline workload; ngp = the hash-grid variant (secondary line)")
     ap.add_argument("--cpu-rays", type=int, default=512, help="ray sample of the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()

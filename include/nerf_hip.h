@@ -181,6 +181,16 @@ int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, i
                      const float* sigma, float* ws, float* ws2, float* const* d_tables,
                      float* const* grads, void* stream);
 
+/* One Adam step over `count` tensors in one launch: torch.optim.Adam with its default
+ * options (no weight decay, no amsgrad), the optimiser of the reference's training loops
+ * (src/train_nerf_llff.py:82 lr 5e-4; src/train_nerf_ngp.py:55 lr 1e-2, eps 1e-15).
+ * Host arrays of device pointers params/grads/exp_avg/exp_avg_sq [count] and element
+ * counts numel [count]; step = 1 for the first step.  Updates params, exp_avg and
+ * exp_avg_sq in place. */
+int nerf_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int64_t* numel, int64_t step, float lr, float beta1,
+                   float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

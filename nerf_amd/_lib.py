@@ -44,6 +44,7 @@ SIGNATURES = {
     "nerf_mlp_ngp_pack": (_I, [_P, _P, _P]),
     "nerf_mlp_ngp_fwd": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_mlp_ngp_bwd": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _P]),
 }
 
 _lib = None

@@ -1,0 +1,63 @@
+"""Adam as one HIP launch over all parameters.
+
+Drop-in for the way the reference's training loops use ``torch.optim.Adam``
+(src/train_nerf_llff.py:82 ``Adam(lr=5e-4)``; src/train_nerf_ngp.py:55
+``Adam(lr=1e-2, eps=1e-15)``): same constructor arguments for the options those
+loops use, same update rule, and a ``state_dict`` with torch's keys
+(``step`` / ``exp_avg`` / ``exp_avg_sq``), so checkpoints move both ways.
+Weight decay, amsgrad and maximize are not implemented and raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 amsgrad: bool = False, maximize: bool = False):
+        if weight_decay != 0.0 or amsgrad or maximize:
+            raise NotImplementedError("FusedAdam implements plain Adam (no weight decay, amsgrad or maximize)")
+        if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False, maximize=False))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise L.NerfHipError("FusedAdam needs contiguous float32 parameters")
+                if p.grad.is_sparse:
+                    raise L.NerfHipError("FusedAdam does not take sparse gradients")
+                L.need_gpu(p)
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            # parameters of one group share the step count unless states were loaded piecemeal
+            by_step = {}
+            for p in ps:
+                by_step.setdefault(int(self.state[p]["step"].item()), []).append(p)
+            for step0, plist in by_step.items():
+                grads = [L.f32c(p.grad) for p in plist]
+                n = len(plist)
+                numel = (C.c_int64 * n)(*[p.numel() for p in plist])
+                L.check(L.lib().nerf_adam_step(
+                    n, L.ptr_array(plist), L.ptr_array(grads), L.ptr_array([self.state[p]["exp_avg"] for p in plist]),
+                    L.ptr_array([self.state[p]["exp_avg_sq"] for p in plist]), numel, step0 + 1, group["lr"],
+                    group["betas"][0], group["betas"][1], group["eps"], L.stream_of(plist[0])), "nerf_adam_step")
+                for p in plist:
+                    self.state[p]["step"] += 1
+        return loss
