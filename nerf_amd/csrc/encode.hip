@@ -211,9 +211,9 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
     int big = 0;
     for (int l = 0; l < levels; ++l) {
         if (res[l] < 1 || sizes[l] < 1) return fail(NERF_EINVAL, "hashgrid: level %d has res=%d size=%d", l, res[l], sizes[l]);
-        if ((unsigned)sizes[l] <= HG_LDS_MAX_ROWS && P >= 4096) {
+        if ((unsigned)sizes[l] <= HG_LDS_MAX_ROWS && P >= 65536) {
             // enough points per workgroup to pay for adding the whole table once per workgroup
-            const int blocks = (int)(P / 4096 < 256 ? P / 4096 : 256);
+            const int blocks = (int)(P / 2048 < 256 ? P / 2048 : 256);
             hipLaunchKernelGGL(hashgrid_bwd_lds_kernel, dim3(blocks), dim3(HG_LDS_THREADS), (size_t)sizes[l] * 2 * sizeof(float),
                                stream, x, P, d_enc, d_tables[l], res[l], (unsigned)sizes[l], l, levels);
             if (int rc = check_launch("hashgrid_scatter(lds)")) return rc;

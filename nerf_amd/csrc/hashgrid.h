@@ -27,10 +27,22 @@ __device__ __forceinline__ unsigned wrap(long long v, int res) {
     return (unsigned)m;
 }
 
+// The same for a coordinate given as an integer-valued float of magnitude below 2^24 (every
+// sample within 32768 grid extents of the origin): the quotient is estimated in float, which
+// can be off by one, and corrected; a 64-bit integer division costs ~100 instructions.
+__device__ __forceinline__ unsigned wrap_small(float fl, int res, float inv_res) {
+    const int v = (int)fl;
+    int m = v - (int)floorf(fl * inv_res) * res;
+    if (m < 0) m += res;
+    if (m >= res) m -= res;
+    return (unsigned)m;
+}
+
 // ((x*1 + y*2654435761 + z*805459861) & 0xFFFFFFFF) % size in the reference's
 // int64 arithmetic equals the 32-bit wrap-around sum (src/utils/hash_grid_encoder.py:39-40).
 __device__ __forceinline__ unsigned hash_row(unsigned cx, unsigned cy, unsigned cz, unsigned size) {
-    return (cx + cy * 2654435761u + cz * 805459861u) % size;
+    const unsigned h = cx + cy * 2654435761u + cz * 805459861u;
+    return (size & (size - 1)) == 0 ? h & (size - 1) : h % size;   // uniform over a level
 }
 
 struct Cell {
@@ -40,18 +52,23 @@ struct Cell {
 
 __device__ __forceinline__ Cell locate(const float* __restrict__ x, int64_t p, int res) {
     Cell c;
+    const float inv_res = 1.0f / (float)res;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float pos = x[p * 3 + k] * (float)res;   // :57
         const float fl = floorf(pos);
-        const long long p0 = (long long)fl;           // :60
         c.w[k] = pos - fl;                             // :64 (before wrapping)
-        c.lo[k] = wrap(p0, res);
-        c.hi[k] = wrap(p0 + 1, res);
+        if (fabsf(fl) < 16777216.0f) {
+            c.lo[k] = wrap_small(fl, res, inv_res);   // :60, :68
+            c.hi[k] = c.lo[k] + 1 == (unsigned)res ? 0u : c.lo[k] + 1;   // (p0 + 1) % res, :69
+        } else {
+            const long long p0 = (long long)fl;
+            c.lo[k] = wrap(p0, res);
+            c.hi[k] = wrap(p0 + 1, res);
+        }
     }
     return c;
 }
-
 
 // Trilinear interpolation of the 8 corner rows in the reference's order: along
 // x, then y, then z (src/utils/hash_grid_encoder.py:95-103), channel by channel.
