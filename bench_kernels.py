@@ -42,13 +42,13 @@ def main():
     from nerf_amd import _lib as L
     from nerf_amd import ops
     from nerf_amd.models.FastNGPNeRF import FastNGPNeRF
-    from oracle import nerf_oracle as O  # only for a camera pose
+    from nerf_amd.Camera import look_at_camera
 
     dev = torch.device("cuda:0")
     R, N, NF = args.rays, 64, 128
     NA = N + NF
     g = torch.Generator().manual_seed(0)
-    c2w = O.look_at_camera(torch.tensor([2.0, -3.0, 1.8]), torch.tensor([4.0, -6.0, 3.6]), torch.tensor([0.0, 0.0, 1.0])).to(dev)
+    c2w = look_at_camera(torch.tensor([2.0, -3.0, 1.8]), torch.tensor([4.0, -6.0, 3.6]), torch.tensor([0.0, 0.0, 1.0])).to(dev)
     pix = torch.randint(0, 640000, (R,), generator=g, dtype=torch.int32).to(dev)
     u = torch.rand(R, N, generator=g).to(dev)
     uf = torch.rand(R, NF, generator=g).to(dev)
