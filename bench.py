@@ -162,7 +162,8 @@ def gpu_main(args):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (dense layers: fp32 operands as 3 bf16 each, 6 bf16 MFMAs per product, fp32 accumulate; "
+                     "weight gradients: exact-f32 MFMA)",
             "data": "synthetic",
             "config": {"workload": "vanilla NeRF 8x256 coarse+fine, Blender-lego-shaped 800x800 camera, "
                                    "64 coarse + 128 fine samples, %d-ray batch per GPU, one training step "

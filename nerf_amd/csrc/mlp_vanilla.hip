@@ -13,18 +13,26 @@
 #include "mlp_common.h"
 
 namespace nerf {
+// The dense layers of the forward and backward-data kernels run on bf16 x 6 MFMAs (dense_x6) when
+// this is set, on the exact-f32 MFMA (dense_shared) otherwise; both are fp32-accurate.
+#ifndef NERF_MLP_X6
+#define NERF_MLP_X6 1
+#endif
+constexpr bool MLP_X6 = NERF_MLP_X6 != 0;
+
 namespace vp {  // float offsets into the packed buffer
-constexpr int T88 = 8 * 16 * 64 * 8;
+constexpr int wfloats(int KT, int OT) { return MLP_X6 ? x6_layer_floats(KT, OT) : KT * 16 * 64 * OT; }
+constexpr int T88 = wfloats(8, 8);
 constexpr int F_L0 = 0;                     // 63(64) -> 256
-constexpr int F_L1 = F_L0 + 2 * 16 * 64 * 8;  // layers 1,2,3
+constexpr int F_L1 = F_L0 + wfloats(2, 8);  // layers 1,2,3
 constexpr int F_L4X = F_L1 + 3 * T88;       // layer 4, x_enc columns
-constexpr int F_L4H = F_L4X + 2 * 16 * 64 * 8;
+constexpr int F_L4H = F_L4X + wfloats(2, 8);
 constexpr int F_L5 = F_L4H + T88;           // layers 5,6,7
 constexpr int F_FEAT = F_L5 + 3 * T88;
 constexpr int F_RGB0F = F_FEAT + T88;       // rgb hidden layer, feature columns (256 -> 128)
-constexpr int F_RGB0D = F_RGB0F + 8 * 16 * 64 * 4;  // view-direction columns (27(32) -> 128)
-constexpr int B_RGB0 = F_RGB0D + 1 * 16 * 64 * 4;   // transposed: 128 -> 256 (feature columns only)
-constexpr int B_FEAT = B_RGB0 + 4 * 16 * 64 * 8;
+constexpr int F_RGB0D = F_RGB0F + wfloats(8, 4);  // view-direction columns (27(32) -> 128)
+constexpr int B_RGB0 = F_RGB0D + wfloats(1, 4);   // transposed: 128 -> 256 (feature columns only)
+constexpr int B_FEAT = B_RGB0 + wfloats(4, 8);
 constexpr int B_L7 = B_FEAT + T88;          // layers 7,6,5,4(h columns),3,2,1
 constexpr int S_BIAS = B_L7 + 7 * T88;      // b0..b7
 constexpr int S_BF = S_BIAS + 8 * 256;
@@ -77,19 +85,44 @@ __device__ __forceinline__ void tile_index(long long P, TileIdx& ix) {
 
 constexpr NextChunks NO_CHUNKS{nullptr, 0, nullptr, 0};
 
+// One dense layer through the weight stream, in the flavour selected by MLP_X6.
+template <int KT, int OT, bool DRAIN = false>
+__device__ __forceinline__ void dense_layer(WeightStream& ws, const float* __restrict__ wp, const NextChunks nx,
+                                            const f32x16 (&in)[KT], f32x16 (&acc)[OT],
+                                            TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
+    if constexpr (MLP_X6) dense_x6<KT, OT, DRAIN>(ws, wp, nx, in, acc, sv);
+    else dense_shared<KT, OT, DRAIN>(ws, wp, nx, in, acc, sv);
+}
+template <int OT_NEXT>
+__device__ __forceinline__ NextChunks chunks_after(const float* after) {
+    if constexpr (MLP_X6) return next_chunks_x6<OT_NEXT>(after);
+    else return next_chunks<OT_NEXT>(after);
+}
+__device__ __forceinline__ void stream_prime(WeightStream& ws, const float* first) {   // a layer of 8 out tiles
+    if constexpr (MLP_X6) x6_prime(ws, first, 6, first + X6_CHUNK_FLOATS, 6);
+    else ws_prime(ws, first, 8, first + WS_CHUNK_FLOATS, 8);
+}
+constexpr int STREAM_LDS_FLOATS = MLP_X6 ? X6_LDS_FLOATS : WS_LDS_FLOATS;
+constexpr int KERNEL_LDS_FLOATS = STREAM_LDS_FLOATS + 4 * TILE_LDS_FLOATS;
+// The chunks of the view-direction layer (1 in-tile, 4 out tiles): two k-steps of 12 KiB, or one chunk of 16 KiB.
+__device__ __forceinline__ NextChunks dir_chunks(const float* first) {
+    if constexpr (MLP_X6) return next_chunks_x6<4>(first);
+    else return NextChunks{first, 4, nullptr, 0};
+}
+
 template <bool SAVE>
 __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dirs,
                                                           long long P, const float* __restrict__ pk,
                                                           float* __restrict__ rgb, float* __restrict__ sigma,
                                                           float* __restrict__ ws, int dirs_div) {
-    __shared__ __attribute__((aligned(16))) float lds[MLP_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[KERNEL_LDS_FLOATS];
     TileIdx ix;
     tile_index(P, ix);
     const int lane = ix.lane, h = ix.h;
     WeightStream wst{lds, 0, ix.wave, lane};
-    const TileBuf tb = tile_buf(lds + WS_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
+    const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
     // the weight stream runs through the packed layers in the order they are used
-    ws_prime(wst, pk + vp::F_L0, 8, pk + vp::F_L0 + WS_CHUNK_FLOATS, 8);
+    stream_prime(wst, pk + vp::F_L0);
     const float x0 = x[3 * ix.lp], x1 = x[3 * ix.lp + 1], x2 = x[3 * ix.lp + 2];
     uint4* mask_out = SAVE ? reinterpret_cast<uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane : nullptr;
 
@@ -109,26 +142,26 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     };
     // layer 0
     fill_rows<8>(acc, pk + vp::S_BIAS, h);
-    dense_shared<2, 8, SAVE>(wst, pk + vp::F_L0, next_chunks<8>(pk + vp::F_L1), xe, acc,
+    dense_layer<2, 8, SAVE>(wst, pk + vp::F_L0, chunks_after<8>(pk + vp::F_L1), xe, acc,
                              tile_save(tb, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64));
     finish_layer(0);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
         const float* wp = pk + vp::F_L1 + (l - 1) * vp::T88;   // followed by the next layer, or by the layer-4 x columns
         fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense_shared<8, 8, SAVE>(wst, wp, next_chunks<8>(wp + vp::T88), hc, acc, rows_of(vw::H + 256 * (l - 1)));
+        dense_layer<8, 8, SAVE>(wst, wp, chunks_after<8>(wp + vp::T88), hc, acc, rows_of(vw::H + 256 * (l - 1)));
         finish_layer(l);
     }
     // skip connection: the layer-4 input is [x_enc | h] (either column order, see the packing)
     fill_rows<8>(acc, pk + vp::S_BIAS + 256 * 4, h);
-    dense_shared<2, 8>(wst, pk + vp::F_L4X, next_chunks<8>(pk + vp::F_L4H), xe, acc);
-    dense_shared<8, 8, SAVE>(wst, pk + vp::F_L4H, next_chunks<8>(pk + vp::F_L5), hc, acc, rows_of(vw::H + 256 * 3));
+    dense_layer<2, 8>(wst, pk + vp::F_L4X, chunks_after<8>(pk + vp::F_L4H), xe, acc);
+    dense_layer<8, 8, SAVE>(wst, pk + vp::F_L4H, chunks_after<8>(pk + vp::F_L5), hc, acc, rows_of(vw::H + 256 * 3));
     finish_layer(4);
 #pragma unroll 1
     for (int l = 5; l < 8; ++l) {
         const float* wp = pk + vp::F_L5 + (l - 5) * vp::T88;   // followed by the next layer, or by the feature layer
         fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense_shared<8, 8, SAVE>(wst, wp, next_chunks<8>(wp + vp::T88), hc, acc, rows_of(vw::H + 256 * (l - 1)));
+        dense_layer<8, 8, SAVE>(wst, wp, chunks_after<8>(wp + vp::T88), hc, acc, rows_of(vw::H + 256 * (l - 1)));
         finish_layer(l);
     }
     // density head: softplus(w.h + b)   (NeRF.py:90)
@@ -136,15 +169,15 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(sp);
     // feature layer (no activation)      (NeRF.py:95)
     fill_rows<8>(acc, pk + vp::S_BF, h);
-    dense_shared<8, 8, SAVE>(wst, pk + vp::F_FEAT, next_chunks<4>(pk + vp::F_RGB0F), hc, acc, rows_of(vw::H + 256 * 7));
+    dense_layer<8, 8, SAVE>(wst, pk + vp::F_FEAT, chunks_after<4>(pk + vp::F_RGB0F), hc, acc, rows_of(vw::H + 256 * 7));
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
     const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
     pe_tiles<1, 4>(de, dirs[3 * dr], dirs[3 * dr + 1], dirs[3 * dr + 2], h);
     f32x16 hr[4];
     fill_rows<4>(hr, pk + vp::S_B1, h);
-    dense_shared<8, 4, SAVE>(wst, pk + vp::F_RGB0F, NextChunks{pk + vp::F_RGB0D, 4, nullptr, 0}, acc, hr, rows_of(vw::FEAT));
-    dense_shared<1, 4, SAVE>(wst, pk + vp::F_RGB0D, NO_CHUNKS, de, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
+    dense_layer<8, 4, SAVE>(wst, pk + vp::F_RGB0F, dir_chunks(pk + vp::F_RGB0D), acc, hr, rows_of(vw::FEAT));
+    dense_layer<1, 4, SAVE>(wst, pk + vp::F_RGB0D, NO_CHUNKS, de, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
     relu_tiles<4>(hr);
     if (SAVE) {
         save_tiles<4>(tb, ws + ix.P32 * vw::HR + ix.tile * 32 * 128, 128, hr);
@@ -164,13 +197,13 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
                                                                const float* __restrict__ rgb,
                                                                const float* __restrict__ sigma,
                                                                const float* __restrict__ ws, float* __restrict__ ws2) {
-    __shared__ __attribute__((aligned(16))) float lds[MLP_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[KERNEL_LDS_FLOATS];
     TileIdx ix;
     tile_index(P, ix);
     const int lane = ix.lane, h = ix.h;
     WeightStream wst{lds, 0, ix.wave, lane};
-    const TileBuf tb = tile_buf(lds + WS_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
-    ws_prime(wst, pk + vp::B_RGB0, 8, pk + vp::B_RGB0 + WS_CHUNK_FLOATS, 8);
+    const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
+    stream_prime(wst, pk + vp::B_RGB0);
     const uint4* mask_in = reinterpret_cast<const uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane;
     float dpre[3], dps = 0.0f;
 #pragma unroll
@@ -208,10 +241,10 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
     auto rows_of = [&](int section) { return tile_save(tb, ws2 + ix.P32 * section + ix.tile * 32 * 256); };
     f32x16 a[8], b[8];
     zero_tiles<8>(a);
-    dense_shared<4, 8, true>(wst, pk + vp::B_RGB0, next_chunks<8>(pk + vp::B_FEAT), dyr, a,
+    dense_layer<4, 8, true>(wst, pk + vp::B_RGB0, chunks_after<8>(pk + vp::B_FEAT), dyr, a,
                              tile_save(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128));   // d feat
     zero_tiles<8>(b);
-    dense_shared<8, 8, true>(wst, pk + vp::B_FEAT, next_chunks<8>(pk + vp::B_L7), a, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
+    dense_layer<8, 8, true>(wst, pk + vp::B_FEAT, chunks_after<8>(pk + vp::B_L7), a, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
 #pragma unroll
     for (int t = 0; t < 8; ++t)                    // ... plus the density head
 #pragma unroll
@@ -226,10 +259,10 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                 // d h_{l-1} = W_l^T d y_l (h columns only at l = 4)
         const float* wp = pk + vp::B_L7 + (7 - l) * vp::T88;
-        NextChunks nx = next_chunks<8>(wp + vp::T88);
+        NextChunks nx = chunks_after<8>(wp + vp::T88);
         if (l == 1) nx = NO_CHUNKS;
         zero_tiles<8>(a);
-        dense_shared<8, 8, true>(wst, wp, nx, b, a, rows_of(vw::DY + l * 256));
+        dense_layer<8, 8, true>(wst, wp, nx, b, a, rows_of(vw::DY + l * 256));
         apply_bits<8>(a, mask_in[(l - 1) * 64]);
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[t] = a[t];
@@ -268,6 +301,7 @@ extern "C" int nerf_mlp_vanilla_pack(const float* const* params, int skip_h_firs
     J.job[n++] = pack_bwd_job(Wf, 256, 256, vp::B_FEAT, 8, 8, 0, 256);
     for (int l = 7; l >= 1; --l)
         J.job[n++] = pack_bwd_job(Wl(l), l == 4 ? 319 : 256, 256, vp::B_L7 + (7 - l) * vp::T88, 8, 8, l == 4 ? h_col : 0, 256);
+    for (int i = 0; i < n; ++i) J.job[i].x6 = MLP_X6;   // every matrix above feeds a dense layer
     for (int l = 0; l < 8; ++l) J.job[n++] = pack_copy_job(bl(l), vp::S_BIAS + 256 * l, 256);
     J.job[n++] = pack_copy_job(bf, vp::S_BF, 256);
     J.job[n++] = pack_copy_job(b1, vp::S_B1, 128);
