@@ -186,6 +186,35 @@ __device__ __forceinline__ void wgrad_mfma(const float (&a)[NTW], const float (&
     }
 }
 
+// Adds a wave's accumulator tiles (and bias sums) to the gradient tensors.
+// dW[n0 + 32nt + rowmap(r,s)][col + i]: per register two 128-byte row segments
+template <int NTW, int KT, int KT2>
+__device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[NTW][KT + KT2], float (&bsum)[NTW], int n0,
+                                             int i, int s) {
+    constexpr int KTT = KT + KT2;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < KTT; ++kt) {
+            const int k = (kt < KT ? 32 * kt : 32 * (kt - KT)) + i;
+            const int col = (kt < KT ? pt.col_off : pt.col_off2) + k;
+            if (k < (kt < KT ? pt.k_valid : pt.k_valid2) && (kt >= KT || k >= pt.k_first)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + 32 * nt + rowmap(r, s);
+                    if (n < pt.n_valid) atomicAdd(pt.dW + (size_t)n * pt.ldW + col, acc[nt][kt][r]);
+                }
+            }
+        }
+    if (pt.dbias) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const float b = bsum[nt] + __shfl_xor(bsum[nt], 32, 64);
+            if (s == 0 && n0 + 32 * nt + i < pt.n_valid) atomicAdd(pt.dbias + n0 + 32 * nt + i, b);
+        }
+    }
+}
+
 template <int NTW, int KT, int KT2, int NW = 4>
 __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
                                            float* lds) {
@@ -260,28 +289,151 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
         });
         cur ^= 1;
     }
-    // dW[n0 + 32nt + rowmap(r,s)][col + i]: per register two 128-byte row segments
+    wgrad_finish<NTW, KT, KT2>(pt, acc, bsum, n0, i, s);
+}
+
+// ------------------------------------------------------- wgrad, bf16 x 6 ----
+// The same contraction on bf16 x 6 MFMAs (see dense_x6 in mlp_common.h): K = 16 points per
+// MFMA, lane (i, hb) holds points 8hb..8hb+7 of column i of dY (A operand) or of X (B
+// operand).  Both operands arrive as fp32 rows in LDS, so every wave splits what it
+// reads: 8 ds_read_b32 and ~50 VALU instructions per operand tile, issued among the
+// 6*NTW MFMAs of the previous tile so that they run in the MFMAs' shadow.
+// Work items of a chunk (32 points = 2 k-steps u): B tiles c = u*KTT + kt, each with
+// 6*NTW MFMAs.  In the region of item c: wait for the raw values of item c+1, request
+// those of item c+2, split item c+1, MFMAs of item c.  The A tiles of k-step 1 are
+// requested in region 0 and split in regions 1..NTW; those of k-step 0 and item 0 are
+// prepared right after the chunk's barrier (the only part that runs without MFMAs).
+#ifndef NERF_WGRAD_X6
+#define NERF_WGRAD_X6 1
+#endif
+
+__device__ __forceinline__ void split_pair(const float (&v)[8], int e, bf16x8& h, bf16x8& m, bf16x8& l) {
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-        for (int kt = 0; kt < KTT; ++kt) {
-            const int k = (kt < KT ? 32 * kt : 32 * (kt - KT)) + i;
-            const int col = (kt < KT ? pt.col_off : pt.col_off2) + k;
-            if (k < (kt < KT ? pt.k_valid : pt.k_valid2) && (kt >= KT || k >= pt.k_first)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + 32 * nt + rowmap(r, s);
-                    if (n < pt.n_valid) atomicAdd(pt.dW + (size_t)n * pt.ldW + col, acc[nt][kt][r]);
-                }
-            }
-        }
-    if (pt.dbias) {
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const float b = bsum[nt] + __shfl_xor(bsum[nt], 32, 64);
-            if (s == 0 && n0 + 32 * nt + i < pt.n_valid) atomicAdd(pt.dbias + n0 + 32 * nt + i, b);
+    for (int i = 0; i < 8; ++i) {
+        if (i / 2 == e) {
+            const __bf16 hh = (__bf16)v[i];
+            const float r1 = v[i] - (float)hh;
+            const __bf16 mm = (__bf16)r1;
+            h[i] = hh;
+            m[i] = mm;
+            l[i] = (__bf16)(r1 - (float)mm);
         }
     }
+}
+
+template <int NTW, int KT, int KT2>
+__device__ __forceinline__ void wgrad_part_x6(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
+                                              float* lds) {
+    using S = WgradShape<NTW, KT, KT2, 4>;
+    constexpr int KTT = KT + KT2, ITEMS = 2 * KTT;
+    const int i = lane & 31, s = lane >> 5;
+    const int n0 = wave * NTW * 32;
+    f32x16 acc[NTW][KTT];
+    float bsum[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        bsum[nt] = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < KTT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][kt][r] = 0.0f;
+    }
+    const WgradSrc<NTW, KT, KT2, 4> src(pt, wave, lane);
+    constexpr int PW = WgradSrc<NTW, KT, KT2, 4>::GROUPS;
+    src.template stage<0, PW>(p_begin, lds);
+    int cur = 0;
+#pragma unroll 1
+    for (long long p = p_begin; p < p_end; p += WG_CH) {
+        __syncthreads();   // this chunk has landed for every wave, and every wave is done with the other buffer
+        const bool more = p + WG_CH < p_end;
+        const float* buf = lds + cur * S::CHUNK;
+        float* nxt = lds + (cur ^ 1) * S::CHUNK;
+        const unsigned r_dy = lds_addr(buf + S::DY_OFF + 8 * s * S::N + n0 + i);
+        const unsigned r_x = lds_addr(buf + S::X_OFF + 8 * s * S::XW + i);
+        const unsigned r_x2 = lds_addr(buf + S::X2_OFF + 8 * s * S::X2W + i);
+        float raw[2][8], raw_a[NTW][8];
+        bf16x8 as[2][NTW][3], bs[2][3];
+        auto load_b = [&](auto cc, float (&o)[8]) {   // raw values of item c: points 16u + 8s + q of X column 32kt + i
+            constexpr int c = decltype(cc)::value, u = c / KTT, kt = c % KTT;
+            static_for<0, 8>([&](auto cq) {
+                constexpr int q = decltype(cq)::value;
+                if constexpr (kt < KT) o[q] = lds_read<((16 * u + q) * S::XW + 32 * kt) * 4>(r_x);
+                else o[q] = lds_read<((16 * u + q) * S::X2W + 32 * (kt - KT)) * 4>(r_x2);
+            });
+        };
+        auto load_a = [&](auto cu, auto cnt, float (&o)[8]) {
+            constexpr int u = decltype(cu)::value, nt = decltype(cnt)::value;
+            static_for<0, 8>([&](auto cq) { o[cq] = lds_read<((16 * u + decltype(cq)::value) * S::N + 32 * nt) * 4>(r_dy); });
+        };
+        auto tie8 = [&](float (&o)[8]) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(o[q]));
+        };
+        // after the barrier: the A tiles of k-step 0 and item 0, then the request for item 1
+        static_for<0, NTW>([&](auto nt) { load_a(std::integral_constant<int, 0>{}, nt, raw_a[nt]); });
+        load_b(std::integral_constant<int, 0>{}, raw[0]);
+        if (more) src.template stage<0, PW / 2>(p + WG_CH, nxt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            tie8(raw_a[nt]);
+            split3(raw_a[nt], as[0][nt][0], as[0][nt][1], as[0][nt][2]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bsum[nt] += raw_a[nt][q];
+        }
+        tie8(raw[0]);
+        split3(raw[0], bs[0][0], bs[0][1], bs[0][2]);
+        if constexpr (ITEMS > 1) load_b(std::integral_constant<int, 1>{}, raw[1]);
+        static_for<0, ITEMS>([&](auto cc) {
+            constexpr int c = decltype(cc)::value, u = c / KTT, kt = c % KTT;
+            // which A tile of k-step 1 is split in this region (requested in region 0)
+            constexpr int a_split = (u == 0 && c >= 1 && c - 1 < NTW) ? c - 1 : -1;
+            constexpr bool a_rest = (u == 0 && c == KTT - 1 && KTT - 1 < NTW);   // narrow shapes: the tiles that found no region
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (c + 1 < ITEMS) tie8(raw[(c + 1) % 2]);
+            if constexpr (a_split >= 0 || a_rest) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) tie8(raw_a[nt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (c + 2 < ITEMS) load_b(std::integral_constant<int, c + 2>{}, raw[c % 2]);
+            if constexpr (c == 0) {
+                static_for<0, NTW>([&](auto nt) { load_a(std::integral_constant<int, 1>{}, nt, raw_a[nt]); });
+                if (more) src.template stage<PW / 2, PW>(p + WG_CH, nxt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // MFMAs of item c with the split of item c+1 (and an A tile) spread between them
+            static_for<0, 6 * NTW>([&](auto cm) {
+                constexpr int m = decltype(cm)::value, term = m / NTW, nt = m % NTW;
+                constexpr int ai = term == 0 ? 2 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 1 : 0;
+                constexpr int bi = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
+                acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[u][nt][ai], bs[c % 2][bi], acc[nt][kt], 0, 0, 0);
+                asm volatile("" : "+a"(acc[nt][kt]));
+                constexpr int SLOTS = 6 * NTW;
+                if constexpr (c + 1 < ITEMS && m < 4)
+                    split_pair(raw[(c + 1) % 2], m, bs[(c + 1) % 2][0], bs[(c + 1) % 2][1], bs[(c + 1) % 2][2]);
+                if constexpr (a_split >= 0 && m >= 4 && m < 8 && SLOTS >= 8)
+                    split_pair(raw_a[a_split], m - 4, as[1][a_split][0], as[1][a_split][1], as[1][a_split][2]);
+            });
+            if constexpr (a_split >= 0) {
+                if constexpr (6 * NTW < 8) split3(raw_a[a_split], as[1][a_split][0], as[1][a_split][1], as[1][a_split][2]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bsum[a_split] += raw_a[a_split][q];
+            }
+            if constexpr (a_rest) {
+                static_for<(KTT - 1 < NTW ? KTT - 1 : NTW), NTW>([&](auto cnt) {
+                    constexpr int nt = decltype(cnt)::value;
+                    split3(raw_a[nt], as[1][nt][0], as[1][nt][1], as[1][nt][2]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bsum[nt] += raw_a[nt][q];
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        cur ^= 1;
+    }
+    wgrad_finish<NTW, KT, KT2>(pt, acc, bsum, n0, i, s);
 }
 
 // shape ids (NTW,KT,KT2,NW): 0 = <2,8,0,4>  1 = <1,8,1,4>  2 = <2,2,0,4>   (a 320-register <2,8,2> tile set does
@@ -309,9 +461,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     if (t0 >= t1) return;   // uniform for the whole workgroup
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     switch (pt.shape) {
+#if NERF_WGRAD_X6
+        case 0: wgrad_part_x6<2, 8, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 1: wgrad_part_x6<1, 8, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 2: wgrad_part_x6<2, 2, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+#else
         case 0: wgrad_part<2, 8, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 1: wgrad_part<1, 8, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 2: wgrad_part<2, 2, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+#endif
         case 3: wgrad_part<1, 1, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 4: wgrad_part<1, 2, 0, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         default: wgrad_part<1, 1, 1, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
@@ -328,7 +486,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
 
 // Relative time per point of a workgroup of each shape (measured for the first three; the
 // narrow shapes run below their MFMA count): the cost model of the slab split.
-static const int kShapeCost[6] = {32, 19, 10, 8, 8, 8};
+static const int kShapeCost[6] = {32, 23, 10, 8, 8, 8};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     // A workgroup takes a whole CU (512 registers per lane), so the grid is sized
