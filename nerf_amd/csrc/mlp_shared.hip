@@ -296,13 +296,17 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
 // The same contraction on bf16 x 6 MFMAs (see dense_x6 in mlp_common.h): K = 16 points per
 // MFMA, lane (i, hb) holds points 8hb..8hb+7 of column i of dY (A operand) or of X (B
 // operand).  Both operands arrive as fp32 rows in LDS, so every wave splits what it
-// reads: 8 ds_read_b32 and ~50 VALU instructions per operand tile, issued among the
-// 6*NTW MFMAs of the previous tile so that they run in the MFMAs' shadow.
-// Work items of a chunk (32 points = 2 k-steps u): B tiles c = u*KTT + kt, each with
-// 6*NTW MFMAs.  In the region of item c: wait for the raw values of item c+1, request
-// those of item c+2, split item c+1, MFMAs of item c.  The A tiles of k-step 1 are
-// requested in region 0 and split in regions 1..NTW; those of k-step 0 and item 0 are
-// prepared right after the chunk's barrier (the only part that runs without MFMAs).
+// reads: 8 ds_read_b32 and ~50 VALU instructions per operand tile, placed among the MFMAs
+// of the previous work item so that they run in the MFMAs' shadow.
+//
+// A chunk (32 points) is 2 k-steps u of J = KTT/GROUP work items, an item being GROUP B
+// tiles with 6*NTW*GROUP MFMAs, ordered so that an accumulator recurs every NTW*GROUP >= 3
+// MFMAs (a dependent 8-pass MFMA issued sooner stalls).  In the region of item c: wait for
+// the raw values of item c+1, request those of item c+2, split item c+1 (and, in region 0,
+// the A tiles of k-step 1) between the MFMAs of item c.  The A tiles of k-step 0 and item 0
+// are prepared right after the chunk's barrier, the only part that runs without MFMAs; the
+// per-chunk state stays local to the chunk (carried across the chunk loop it costs twice
+// the registers, and a spilled operand of an asm load is spilled before it has arrived).
 #ifndef NERF_WGRAD_X6
 #define NERF_WGRAD_X6 1
 #endif
@@ -321,11 +325,12 @@ __device__ __forceinline__ void split_pair(const float (&v)[8], int e, bf16x8& h
     }
 }
 
-template <int NTW, int KT, int KT2>
+template <int NTW, int KT, int KT2, int GROUP>
 __device__ __forceinline__ void wgrad_part_x6(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
                                               float* lds) {
     using S = WgradShape<NTW, KT, KT2, 4>;
-    constexpr int KTT = KT + KT2, ITEMS = 2 * KTT;
+    constexpr int KTT = KT + KT2, J = KTT / GROUP, ITEMS = 2 * J, NM = 6 * NTW * GROUP;
+    static_assert(KTT % GROUP == 0 && NM >= 4 * (GROUP + NTW), "item shape");
     const int i = lane & 31, s = lane >> 5;
     const int n0 = wave * NTW * 32;
     f32x16 acc[NTW][KTT];
@@ -351,84 +356,79 @@ __device__ __forceinline__ void wgrad_part_x6(const WgradPart& pt, long long p_b
         const unsigned r_dy = lds_addr(buf + S::DY_OFF + 8 * s * S::N + n0 + i);
         const unsigned r_x = lds_addr(buf + S::X_OFF + 8 * s * S::XW + i);
         const unsigned r_x2 = lds_addr(buf + S::X2_OFF + 8 * s * S::X2W + i);
-        float raw[2][8], raw_a[NTW][8];
-        bf16x8 as[2][NTW][3], bs[2][3];
-        auto load_b = [&](auto cc, float (&o)[8]) {   // raw values of item c: points 16u + 8s + q of X column 32kt + i
-            constexpr int c = decltype(cc)::value, u = c / KTT, kt = c % KTT;
-            static_for<0, 8>([&](auto cq) {
-                constexpr int q = decltype(cq)::value;
-                if constexpr (kt < KT) o[q] = lds_read<((16 * u + q) * S::XW + 32 * kt) * 4>(r_x);
-                else o[q] = lds_read<((16 * u + q) * S::X2W + 32 * (kt - KT)) * 4>(r_x2);
+        float raw[2][GROUP][8], raw_a[2][NTW][8];
+        bf16x8 as[2][NTW][3], bs[2][GROUP][3];
+        auto load_item = [&](auto cc, float (&o)[GROUP][8]) {   // points 16u + 8s + q of X columns 32kt + i
+            constexpr int c = decltype(cc)::value, u = c / J;
+            static_for<0, GROUP>([&](auto cg) {
+                constexpr int kt = GROUP * (c % J) + decltype(cg)::value;
+                static_for<0, 8>([&](auto cq) {
+                    constexpr int q = decltype(cq)::value;
+                    if constexpr (kt < KT) o[cg][q] = lds_read<((16 * u + q) * S::XW + 32 * kt) * 4>(r_x);
+                    else o[cg][q] = lds_read<((16 * u + q) * S::X2W + 32 * (kt - KT)) * 4>(r_x2);
+                });
             });
         };
-        auto load_a = [&](auto cu, auto cnt, float (&o)[8]) {
-            constexpr int u = decltype(cu)::value, nt = decltype(cnt)::value;
-            static_for<0, 8>([&](auto cq) { o[cq] = lds_read<((16 * u + decltype(cq)::value) * S::N + 32 * nt) * 4>(r_dy); });
+        auto load_a = [&](auto cu, float (&o)[NTW][8]) {
+            constexpr int u = decltype(cu)::value;
+            static_for<0, NTW>([&](auto cnt) {
+                static_for<0, 8>([&](auto cq) {
+                    o[cnt][cq] = lds_read<((16 * u + decltype(cq)::value) * S::N + 32 * decltype(cnt)::value) * 4>(r_dy);
+                });
+            });
         };
         auto tie8 = [&](float (&o)[8]) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(o[q]));
         };
-        // after the barrier: the A tiles of k-step 0 and item 0, then the request for item 1
-        static_for<0, NTW>([&](auto nt) { load_a(std::integral_constant<int, 0>{}, nt, raw_a[nt]); });
-        load_b(std::integral_constant<int, 0>{}, raw[0]);
+        // after the barrier: requests for both k-steps' A tiles and item 0; half of the next chunk's copies
+        load_a(std::integral_constant<int, 0>{}, raw_a[0]);
+        load_item(std::integral_constant<int, 0>{}, raw[0]);
+        load_a(std::integral_constant<int, 1>{}, raw_a[1]);
         if (more) src.template stage<0, PW / 2>(p + WG_CH, nxt);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            tie8(raw_a[nt]);
-            split3(raw_a[nt], as[0][nt][0], as[0][nt][1], as[0][nt][2]);
+            tie8(raw_a[0][nt]);
+            tie8(raw_a[1][nt]);
+            split3(raw_a[0][nt], as[0][nt][0], as[0][nt][1], as[0][nt][2]);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) bsum[nt] += raw_a[nt][q];
+            for (int q = 0; q < 8; ++q) bsum[nt] += raw_a[0][nt][q] + raw_a[1][nt][q];
         }
-        tie8(raw[0]);
-        split3(raw[0], bs[0][0], bs[0][1], bs[0][2]);
-        if constexpr (ITEMS > 1) load_b(std::integral_constant<int, 1>{}, raw[1]);
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) {
+            tie8(raw[0][g]);
+            split3(raw[0][g], bs[0][g][0], bs[0][g][1], bs[0][g][2]);
+        }
+        if constexpr (ITEMS > 1) load_item(std::integral_constant<int, 1>{}, raw[1]);
         static_for<0, ITEMS>([&](auto cc) {
-            constexpr int c = decltype(cc)::value, u = c / KTT, kt = c % KTT;
-            // which A tile of k-step 1 is split in this region (requested in region 0)
-            constexpr int a_split = (u == 0 && c >= 1 && c - 1 < NTW) ? c - 1 : -1;
-            constexpr bool a_rest = (u == 0 && c == KTT - 1 && KTT - 1 < NTW);   // narrow shapes: the tiles that found no region
+            constexpr int c = decltype(cc)::value, u = c / J, k0 = GROUP * (c % J);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (c + 1 < ITEMS) tie8(raw[(c + 1) % 2]);
-            if constexpr (a_split >= 0 || a_rest) {
+            if constexpr (c + 1 < ITEMS) {
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) tie8(raw_a[nt]);
+                for (int g = 0; g < GROUP; ++g) tie8(raw[(c + 1) % 2][g]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (c + 2 < ITEMS) load_b(std::integral_constant<int, c + 2>{}, raw[c % 2]);
+            if constexpr (c + 2 < ITEMS) load_item(std::integral_constant<int, c + 2>{}, raw[c % 2]);
             if constexpr (c == 0) {
-                static_for<0, NTW>([&](auto nt) { load_a(std::integral_constant<int, 1>{}, nt, raw_a[nt]); });
                 if (more) src.template stage<PW / 2, PW>(p + WG_CH, nxt);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // MFMAs of item c with the split of item c+1 (and an A tile) spread between them
-            static_for<0, 6 * NTW>([&](auto cm) {
-                constexpr int m = decltype(cm)::value, term = m / NTW, nt = m % NTW;
+            // MFMAs of item c, term-major; between them the splits of item c+1 and, in region 0, of the A tiles of k-step 1
+            static_for<0, NM>([&](auto cm) {
+                constexpr int m = decltype(cm)::value, term = m / (NTW * GROUP), nt = (m / GROUP) % NTW, g = m % GROUP;
                 constexpr int ai = term == 0 ? 2 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 1 : 0;
                 constexpr int bi = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
-                acc[nt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[u][nt][ai], bs[c % 2][bi], acc[nt][kt], 0, 0, 0);
-                asm volatile("" : "+a"(acc[nt][kt]));
-                constexpr int SLOTS = 6 * NTW;
-                if constexpr (c + 1 < ITEMS && m < 4)
-                    split_pair(raw[(c + 1) % 2], m, bs[(c + 1) % 2][0], bs[(c + 1) % 2][1], bs[(c + 1) % 2][2]);
-                if constexpr (a_split >= 0 && m >= 4 && m < 8 && SLOTS >= 8)
-                    split_pair(raw_a[a_split], m - 4, as[1][a_split][0], as[1][a_split][1], as[1][a_split][2]);
+                acc[nt][k0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[u][nt][ai], bs[c % 2][g][bi], acc[nt][k0 + g], 0, 0, 0);
+                asm volatile("" : "+a"(acc[nt][k0 + g]));
+                if constexpr (c + 1 < ITEMS && m < 4 * GROUP)
+                    split_pair(raw[(c + 1) % 2][m / 4], m % 4, bs[(c + 1) % 2][m / 4][0], bs[(c + 1) % 2][m / 4][1], bs[(c + 1) % 2][m / 4][2]);
+                if constexpr (c == 0 && m >= 4 * GROUP && m < 4 * (GROUP + NTW)) {
+                    constexpr int e = m - 4 * GROUP, nta = e / 4;
+                    split_pair(raw_a[1][nta], e % 4, as[1][nta][0], as[1][nta][1], as[1][nta][2]);
+                }
             });
-            if constexpr (a_split >= 0) {
-                if constexpr (6 * NTW < 8) split3(raw_a[a_split], as[1][a_split][0], as[1][a_split][1], as[1][a_split][2]);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) bsum[a_split] += raw_a[a_split][q];
-            }
-            if constexpr (a_rest) {
-                static_for<(KTT - 1 < NTW ? KTT - 1 : NTW), NTW>([&](auto cnt) {
-                    constexpr int nt = decltype(cnt)::value;
-                    split3(raw_a[nt], as[1][nt][0], as[1][nt][1], as[1][nt][2]);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) bsum[nt] += raw_a[nt][q];
-                });
-            }
             __builtin_amdgcn_sched_barrier(0);
         });
         cur ^= 1;
@@ -462,9 +462,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     switch (pt.shape) {
 #if NERF_WGRAD_X6
-        case 0: wgrad_part_x6<2, 8, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        case 1: wgrad_part_x6<1, 8, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        case 2: wgrad_part_x6<2, 2, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 0: wgrad_part_x6<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 1: wgrad_part_x6<1, 8, 1, 3>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 2: wgrad_part_x6<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
 #else
         case 0: wgrad_part<2, 8, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 1: wgrad_part<1, 8, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
