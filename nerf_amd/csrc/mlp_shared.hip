@@ -77,7 +77,7 @@ int launch_pack(const PackJobs& jobs, float* packed, hipStream_t stream) {
 // of cover for an HBM miss under load).  MFMA operands are then conflict-free
 // ds_read_b32 (32 consecutive floats per lane half), fetched one k-step ahead.
 constexpr int WG_CH = 32;                          // points per chunk
-constexpr int WG_LDS_FLOATS = 2 * WG_CH * (256 + 256);  // two buffers of the largest shape (128 KiB)
+constexpr int WG_LDS_FLOATS = 3 * 16 * (3 * 256 + 4);   // three k-steps of 16 split operand tiles (145 KiB); also holds two raw chunks
 
 // NW = waves along the output dimension (N = NW*NTW*32 columns of dY); the other
 // 4/NW wave groups split the k-steps of every chunk between them.
@@ -190,7 +190,7 @@ __device__ __forceinline__ void wgrad_mfma(const float (&a)[NTW], const float (&
 // dW[n0 + 32nt + rowmap(r,s)][col + i]: per register two 128-byte row segments
 template <int NTW, int KT, int KT2>
 __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[NTW][KT + KT2], float (&bsum)[NTW], int n0,
-                                             int i, int s) {
+                                             int i, int s, bool with_bias = true) {
     constexpr int KTT = KT + KT2;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -206,7 +206,7 @@ __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[
                 }
             }
         }
-    if (pt.dbias) {
+    if (pt.dbias && with_bias) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const float b = bsum[nt] + __shfl_xor(bsum[nt], 32, 64);
@@ -307,6 +307,9 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
 // are prepared right after the chunk's barrier, the only part that runs without MFMAs; the
 // per-chunk state stays local to the chunk (carried across the chunk loop it costs twice
 // the registers, and a spilled operand of an asm load is spilled before it has arrived).
+#ifndef NERF_WGRAD_PK
+#define NERF_WGRAD_PK 1
+#endif
 #ifndef NERF_WGRAD_X6
 #define NERF_WGRAD_X6 1
 #endif
@@ -436,6 +439,210 @@ __device__ __forceinline__ void wgrad_part_x6(const WgradPart& pt, long long p_b
     wgrad_finish<NTW, KT, KT2>(pt, acc, bsum, n0, i, s);
 }
 
+// ---- The same product with the operands split once per workgroup ----------------------------------
+// Above, every wave splits each X tile it multiplies with: four times the work per workgroup, and
+// the conversions (~6.5 instructions per value) rival the MFMAs.  Here a k-step (16 points) of dY and X
+// is loaded into registers once, split there, and stored to LDS as ready bf16 operands:
+// [tile][h, m, l][operand lane][8 points], which every wave then reads with one 16-byte load per operand.
+// Three buffers of one k-step rotate: k-step s is multiplied while k-step s+2 is split and stored and
+// k-step s+4 is on its way from memory, so the one barrier per k-step only has skew to wait for.
+// A tile's stride is padded by 16 bytes so that the four tiles a wave stores at once fall on different banks.
+constexpr int PK_TILE_BYTES = 3 * 1024 + 16;
+constexpr int PK_BUF_BYTES = 16 * PK_TILE_BYTES;
+static_assert(3 * PK_BUF_BYTES <= WG_LDS_FLOATS * 4, "operand buffers exceed the LDS allocation");
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF_BYTES>
+__device__ __forceinline__ void lds_write_u4(unsigned addr, u32x4 v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF_BYTES) : "memory");
+}
+// {bf16(a), bf16(b)} rounded to nearest even, a in the low half
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int NTW, int KT, int KT2, int GROUP>
+__device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
+                                              float* lds) {
+    constexpr int NT = 4 * NTW, KTT = KT + KT2, TILES = NT + KTT, J = KTT / GROUP, NM = 6 * NTW * GROUP;
+    static_assert(TILES <= 16 && KTT % GROUP == 0, "shape");
+    const int i = lane & 31, s = lane >> 5;
+    const int n0 = wave * NTW * 32;
+    f32x16 acc[NTW][KTT];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < KTT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][kt][r] = 0.0f;
+
+    // producer role: columns 4pj .. 4pj+3 of tile T (dY tiles first, then X, then X2), points 8ps .. 8ps+7 of a k-step
+    const int pj = (lane & 3) | ((lane >> 2) & 4), ptl = (lane >> 2) & 3, ps = lane >> 5;
+    const int T = 4 * wave + ptl;
+    const bool active = T < TILES;
+    const float* src = pt.dY + 4 * pj;   // lanes without a tile load (and store) something harmless
+    long long ld = pt.ldY;
+    if (T < NT) {
+        src = pt.dY + 32 * T + 4 * pj;
+        ld = pt.ldY;
+    } else if (T < NT + KT) {
+        src = pt.X + 32 * (T - NT) + 4 * pj;
+        ld = pt.ldX;
+    } else if (active) {
+        src = pt.X2 + 32 * (T - NT - KT) + 4 * pj;
+        ld = pt.ldX2;
+    }
+    src += 8 * ps * ld;
+    const unsigned lds0 = lds_addr(lds);
+    const unsigned wr_off = T * PK_TILE_BYTES + (4 * pj + 32 * ps) * 16;
+    const unsigned rd_a_off = NTW * wave * PK_TILE_BYTES + lane * 16, rd_b_off = lane * 16;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of this lane's dY columns (the bias gradient)
+    float4 R[2][8];
+    // Request row q of a k-step.  Never skipped, so that the compiler's count of requests in flight stays exact:
+    // past the end the last k-step is read again and ignored.
+    auto load_row = [&](auto cu, auto cq, long long p) {
+        const long long pc = p < p_end ? p : p_end - 16;
+        R[decltype(cu)::value][decltype(cq)::value] = *reinterpret_cast<const float4*>(src + (pc + decltype(cq)::value) * ld);
+    };
+    auto load_raw = [&](auto cu, long long p) { static_for<0, 8>([&](auto cq) { load_row(cu, cq, p); }); };
+    // Splitting a k-step is 60 chunks of at most six mutually independent instructions, one chunk per MFMA:
+    // a dependent instruction issued right behind its producer waits ~9 clocks and holds up the MFMA queued
+    // behind it, whereas up to six independent ones issue under an MFMA for free.  Chunk 14e + 7g + level
+    // is one level of the split of rows 2e, 2e+1 of columns 2g, 2g+1 (bf16 pair h, its residual, pair m, its
+    // residual, pair l); chunks 56-59 store the four finished columns.  After the last chunk of a row pair its
+    // rows of the k-step after next are requested, so the requests spread over the k-step.
+    unsigned PH[4][4], PM[4][4], PL[4][4];   // [column][row pair], two bf16 each
+    float t_r0[2], t_r1[2], t_f0[2], t_f1[2], t_sum[2];
+    auto chunk = [&](auto cu, auto ck, unsigned wr, float live, long long p_next) {
+        constexpr int u = decltype(cu)::value, k = decltype(ck)::value;
+        if constexpr (k < 56) {
+            constexpr int e = k / 14, g = (k % 14) / 7, lv = k % 7;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = 2 * g + j;
+                const float x0 = c == 0 ? R[u][2 * e].x : c == 1 ? R[u][2 * e].y : c == 2 ? R[u][2 * e].z : R[u][2 * e].w;
+                const float x1 = c == 0 ? R[u][2 * e + 1].x : c == 1 ? R[u][2 * e + 1].y : c == 2 ? R[u][2 * e + 1].z : R[u][2 * e + 1].w;
+                if constexpr (lv == 0) {
+                    PH[c][e] = cvt_pk_bf16(x0, x1);
+                    t_sum[j] = x0 + x1;
+                } else if constexpr (lv == 1) {
+                    t_f0[j] = __uint_as_float(PH[c][e] << 16);
+                    t_f1[j] = __uint_as_float(PH[c][e] & 0xffff0000u);
+                    bsum[c] = fmaf(live, t_sum[j], bsum[c]);
+                } else if constexpr (lv == 2) {
+                    t_r0[j] = x0 - t_f0[j];
+                    t_r1[j] = x1 - t_f1[j];
+                } else if constexpr (lv == 3) {
+                    PM[c][e] = cvt_pk_bf16(t_r0[j], t_r1[j]);
+                } else if constexpr (lv == 4) {
+                    t_f0[j] = __uint_as_float(PM[c][e] << 16);
+                    t_f1[j] = __uint_as_float(PM[c][e] & 0xffff0000u);
+                } else if constexpr (lv == 5) {
+                    t_r0[j] = t_r0[j] - t_f0[j];
+                    t_r1[j] = t_r1[j] - t_f1[j];
+                } else {
+                    PL[c][e] = cvt_pk_bf16(t_r0[j], t_r1[j]);
+                }
+            }
+            if constexpr (k % 14 == 13) {
+                load_row(cu, std::integral_constant<int, 2 * e>{}, p_next);
+                load_row(cu, std::integral_constant<int, 2 * e + 1>{}, p_next);
+            }
+        } else {
+            constexpr int c = k - 56;
+            lds_write_u4<c * 16>(wr, u32x4{PH[c][0], PH[c][1], PH[c][2], PH[c][3]});
+            lds_write_u4<c * 16 + 1024>(wr, u32x4{PM[c][0], PM[c][1], PM[c][2], PM[c][3]});
+            lds_write_u4<c * 16 + 2048>(wr, u32x4{PL[c][0], PL[c][1], PL[c][2], PL[c][3]});
+        }
+    };
+    bf16x8 as[2][NTW][3], bs[2][GROUP][3];
+    auto read_a = [&](unsigned buf, bf16x8 (&o)[NTW][3]) {
+        static_for<0, NTW * 3>([&](auto ce) {
+            constexpr int e = decltype(ce)::value;
+            o[e / 3][e % 3] = lds_read_bf8<(e / 3) * PK_TILE_BYTES + (e % 3) * 1024>(buf + rd_a_off);
+        });
+    };
+    auto read_b = [&](unsigned buf, auto cc, bf16x8 (&o)[GROUP][3]) {
+        constexpr int k0 = GROUP * decltype(cc)::value;
+        static_for<0, GROUP * 3>([&](auto ce) {
+            constexpr int e = decltype(ce)::value;
+            o[e / 3][e % 3] = lds_read_bf8<(NT + k0 + e / 3) * PK_TILE_BYTES + (e % 3) * 1024>(buf + rd_b_off);
+        });
+    };
+
+    // prologue: k-steps 0 and 1 into buffers 0 and 1, k-steps 2 and 3 requested
+    load_raw(std::integral_constant<int, 0>{}, p_begin);
+    load_raw(std::integral_constant<int, 1>{}, p_begin + 16);
+    static_for<0, 60>([&](auto ck) { chunk(std::integral_constant<int, 0>{}, ck, lds0 + wr_off, 1.0f, p_begin + 32); });
+    static_for<0, 60>([&](auto ck) {
+        chunk(std::integral_constant<int, 1>{}, ck, lds0 + PK_BUF_BYTES + wr_off, 1.0f, p_begin + 48);
+    });
+    lgkm_wait();
+    __syncthreads();
+    read_a(lds0, as[0]);
+    read_b(lds0, std::integral_constant<int, 0>{}, bs[0]);
+    int b = 0;
+#pragma unroll 1
+    for (long long p = p_begin; p < p_end; p += 32) {
+        static_for<0, 2>([&](auto cu) {
+            constexpr int u = decltype(cu)::value;
+            const unsigned cur = lds0 + b * PK_BUF_BYTES, nxt = lds0 + wrap3(b + 1) * PK_BUF_BYTES;
+            const unsigned wr = lds0 + wrap3(b + 2) * PK_BUF_BYTES + wr_off;
+            const float live = p + (u + 2) * 16 < p_end ? 1.0f : 0.0f;   // is there a k-step to store
+            static_for<0, J>([&](auto cc) {
+                constexpr int c = decltype(cc)::value, par = (u * J + c) % 2, k0 = GROUP * c;
+                __builtin_amdgcn_sched_barrier(0);
+                lgkm_wait();
+#pragma unroll
+                for (int g = 0; g < GROUP; ++g)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) asm volatile("" : "+v"(bs[par][g][e]));
+                if constexpr (c == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) asm volatile("" : "+v"(as[u][nt][e]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c + 1 < J) {
+                    read_b(cur, std::integral_constant<int, c + 1>{}, bs[par ^ 1]);
+                } else {   // the next k-step's dY tiles and first item; its buffer was complete a barrier ago
+                    read_a(nxt, as[u ^ 1]);
+                    read_b(nxt, std::integral_constant<int, 0>{}, bs[par ^ 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, NM>([&](auto cm) {
+                    constexpr int m = decltype(cm)::value, term = m / (NTW * GROUP), nt = (m / GROUP) % NTW, g = m % GROUP;
+                    constexpr int ai = term == 0 ? 2 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 1 : 0;
+                    constexpr int bi = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
+                    acc[nt][k0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[u][nt][ai], bs[par][g][bi], acc[nt][k0 + g], 0, 0, 0);
+                    asm volatile("" : "+a"(acc[nt][k0 + g]));
+                    constexpr int step = c * NM + m;   // position within the k-step: its share of the 60 chunks
+                    static_for<(step * 60 + J * NM - 1) / (J * NM), ((step + 1) * 60 + J * NM - 1) / (J * NM)>([&](auto ck) {
+                        chunk(cu, ck, wr, live, p + (u + 4) * 16);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            lgkm_wait();
+            __syncthreads();
+            b = wrap3(b + 1);
+        });
+    }
+    float zero[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) zero[nt] = 0.0f;
+    wgrad_finish<NTW, KT, KT2>(pt, acc, zero, n0, i, s, false);
+    if (pt.dbias && T < NT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (32 * T + 4 * pj + c < pt.n_valid) atomicAdd(pt.dbias + 32 * T + 4 * pj + c, bsum[c]);
+    }
+}
+
 // shape ids (NTW,KT,KT2,NW): 0 = <2,8,0,4>  1 = <1,8,1,4>  2 = <2,2,0,4>   (a 320-register <2,8,2> tile set does
 // not allocate without spills);  small layers of the hash-grid model: 3 = <1,1,0,2>  4 = <1,2,0,1>  5 = <1,1,1,2>
 #ifdef NERF_WG_TIMING
@@ -461,7 +668,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     if (t0 >= t1) return;   // uniform for the whole workgroup
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     switch (pt.shape) {
-#if NERF_WGRAD_X6
+#if NERF_WGRAD_PK
+        case 0: wgrad_part_pk<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 1: wgrad_part_pk<1, 8, 1, 3>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 2: wgrad_part_x6<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;   // 24 MFMAs per k-step cannot hide the loads of the shared split
+#elif NERF_WGRAD_X6
         case 0: wgrad_part_x6<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 1: wgrad_part_x6<1, 8, 1, 3>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 2: wgrad_part_x6<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
@@ -486,7 +697,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
 
 // Relative time per point of a workgroup of each shape (measured for the first three; the
 // narrow shapes run below their MFMA count): the cost model of the slab split.
-static const int kShapeCost[6] = {32, 23, 10, 8, 8, 8};
+static const int kShapeCost[6] = {32, 25, 15, 8, 8, 8};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     // A workgroup takes a whole CU (512 registers per lane), so the grid is sized
