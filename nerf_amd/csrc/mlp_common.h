@@ -321,6 +321,13 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m
         l[i] = (__bf16)(r1 - (float)mm);
     }
 }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// {bf16(a), bf16(b)} rounded to nearest even, a in the low half
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int OFF_BYTES>
 __device__ __forceinline__ bf16x8 lds_read_bf8(unsigned addr) {
     bf16x8 r;
@@ -348,7 +355,7 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
     static_assert(OT % 4 == 0, "out tiles are processed four at a time");
     constexpr int S = 2 * KT, G = OT / 4, CHF = OT * 3 * 256, PW = CHF / 1024;
     bf16x8 a[2][12];                 // operands of a group of 4 out tiles (tile*3 + split), double-buffered
-    bf16x8 b[3], bn[3];              // this k-step's B splits (h, m, l) and the next one's
+    bf16x8 b[3];                     // this k-step's B splits (h, m, l); the next one's are built in nh, nm, nl
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};   // two row blocks on their way out
     auto split_step = [&](auto cs, bf16x8 (&o)[3]) {
         constexpr int s = decltype(cs)::value;
@@ -356,6 +363,28 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = in[s / 2][8 * (s % 2) + i];
         split3(v, o[0], o[1], o[2]);
+    };
+    // The same split for the next k-step in eleven chunks of four independent instructions, one chunk every few
+    // MFMAs: an instruction issued right behind the one it depends on waits ~9 clocks with the MFMA behind it.
+    u32x4 nh, nm, nl;
+    float sr0[4], sr1[4], sf0[4], sf1[4];
+    auto split_chunk = [&](auto cs, auto ck) {
+        constexpr int s = decltype(cs)::value, k = decltype(ck)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x0 = in[s / 2][8 * (s % 2) + 2 * i], x1 = in[s / 2][8 * (s % 2) + 2 * i + 1];
+            if constexpr (k == 0) nh[i] = cvt_pk_bf16(x0, x1);
+            else if constexpr (k == 1) sf0[i] = __uint_as_float(nh[i] << 16);
+            else if constexpr (k == 2) sf1[i] = __uint_as_float(nh[i] & 0xffff0000u);
+            else if constexpr (k == 3) sr0[i] = x0 - sf0[i];
+            else if constexpr (k == 4) sr1[i] = x1 - sf1[i];
+            else if constexpr (k == 5) nm[i] = cvt_pk_bf16(sr0[i], sr1[i]);
+            else if constexpr (k == 6) sf0[i] = __uint_as_float(nm[i] << 16);
+            else if constexpr (k == 7) sf1[i] = __uint_as_float(nm[i] & 0xffff0000u);
+            else if constexpr (k == 8) sr0[i] = sr0[i] - sf0[i];
+            else if constexpr (k == 9) sr1[i] = sr1[i] - sf1[i];
+            else nl[i] = cvt_pk_bf16(sr0[i], sr1[i]);
+        }
     };
     auto read_group = [&](unsigned rd, auto cg, bf16x8 (&o)[12]) {
         constexpr int g = decltype(cg)::value;
@@ -390,6 +419,10 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
             __builtin_amdgcn_sched_barrier(0);
             acc[4 * g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[2], b[0], acc[4 * g], 0, 0, 0);   // l * h of tile 0
             asm volatile("" : "+a"(acc[4 * g]));
+            if constexpr (s + 1 < S) {
+                static_for<(24 * g * 11 + 24 * G - 1) / (24 * G), ((24 * g + 1) * 11 + 24 * G - 1) / (24 * G)>(
+                    [&](auto ck) { split_chunk(std::integral_constant<int, s + 1>{}, ck); });
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (DRAIN && g == 0) {
                 if constexpr (s > 0) {   // the two row blocks read during the previous k-step
@@ -421,7 +454,6 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
             if constexpr (g + 1 < G) read_group(rd, std::integral_constant<int, g + 1>{}, nxt);
             else if constexpr (s + 1 < S) read_group(rd_next, std::integral_constant<int, 0>{}, nxt);
             if constexpr (g == G - 1) {
-                if constexpr (s + 1 < S) split_step(std::integral_constant<int, s + 1>{}, bn);
                 if constexpr (DRAIN) {
                     constexpr int k0 = 2 * (s % 2);
                     d0 = lds_read4<8 * k0 * TILE_LD * 4>(sv.tb.rd);
@@ -436,13 +468,19 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                 constexpr int bs = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
                 acc[4 * g + o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[3 * o + as], b[bs], acc[4 * g + o], 0, 0, 0);
                 asm volatile("" : "+a"(acc[4 * g + o]));
+                if constexpr (s + 1 < S) {
+                    constexpr int slot = 24 * g + m;
+                    static_for<(slot * 11 + 24 * G - 1) / (24 * G), ((slot + 1) * 11 + 24 * G - 1) / (24 * G)>(
+                        [&](auto ck) { split_chunk(std::integral_constant<int, s + 1>{}, ck); });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             });
             __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (s + 1 < S) {
-            b[0] = bn[0];
-            b[1] = bn[1];
-            b[2] = bn[2];
+            b[0] = __builtin_bit_cast(bf16x8, nh);
+            b[1] = __builtin_bit_cast(bf16x8, nm);
+            b[2] = __builtin_bit_cast(bf16x8, nl);
         }
     });
     if constexpr (DRAIN) {   // the last two row blocks

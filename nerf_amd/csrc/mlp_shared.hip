@@ -451,17 +451,11 @@ constexpr int PK_TILE_BYTES = 3 * 1024 + 16;
 constexpr int PK_BUF_BYTES = 16 * PK_TILE_BYTES;
 static_assert(3 * PK_BUF_BYTES <= WG_LDS_FLOATS * 4, "operand buffers exceed the LDS allocation");
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int OFF_BYTES>
 __device__ __forceinline__ void lds_write_u4(unsigned addr, u32x4 v) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF_BYTES) : "memory");
 }
-// {bf16(a), bf16(b)} rounded to nearest even, a in the low half
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+
 
 template <int NTW, int KT, int KT2, int GROUP>
 __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
