@@ -42,6 +42,15 @@ const char* nerf_last_error(void);
 int nerf_raygen(const float* c2w, float fx, float fy, float cx, float cy, int H, int W,
                 const int32_t* pix, int64_t R, float* rays_o, float* rays_d, void* stream);
 
+/* A ray batch drawn across the images of a dataset, which the reference forms one image at a
+ * time (Camera.get_rays per DataLoader item, src/train_nerf_skow.py:132-146, src/train_nerf_llff.py:106-111).
+ * cams: [n_cams][16] = 12 floats of the 3x4 pose, fx, fy, cx, cy; ray r looks through pixel pix[r]
+ * (row*W + col, all images H x W) of camera cam_id[r].  images: [n_cams][H*W][3] or NULL; when given,
+ * rgb [R,3] receives the pixels' colours.  Ids are the caller's to keep in range. */
+int nerf_raygen_multi(const float* cams, int n_cams, int H, int W, const int32_t* cam_id,
+                      const int32_t* pix, int64_t R, const float* images, float* rays_o,
+                      float* rays_d, float* rgb, void* stream);
+
 /* Camera.sample_points_along_rays, src/Camera.py:127-141.  z_lin: the N base
  * depths (torch.linspace(near, far, N), computed by the caller so that the
  * values are the reference's bit for bit).  u: [R,N] uniforms in [0,1) that the

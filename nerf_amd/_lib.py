@@ -23,6 +23,7 @@ SIGNATURES = {
     "nerf_abi_version": (_I, []),
     "nerf_last_error": (C.c_char_p, []),
     "nerf_raygen": (_I, [_P, _F, _F, _F, _F, _I, _I, _P, _L, _P, _P, _P]),
+    "nerf_raygen_multi": (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P]),
     "nerf_stratified_sample": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nerf_raygen_sample": (_I, [_P, _F, _F, _F, _F, _I, _I, _P, _L, _P, _P, _I, _P, _P, _P, _P, _P]),
     "nerf_pdf_sample": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),

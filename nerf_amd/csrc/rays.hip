@@ -42,6 +42,33 @@ __global__ void raygen_kernel(const float* __restrict__ c2w, float fx, float fy,
     }
 }
 
+// Rays of a batch drawn across many cameras: ray r looks through pixel pix[r] of camera cam_id[r].
+// cams: [n][16] = the 12 floats of the 3x4 pose, then fx, fy, cx, cy.  With images ([n][H*W][3]) the
+// pixel's colour is gathered alongside (the training target), so a batch costs one pass.
+__global__ void raygen_multi_kernel(const float* __restrict__ cams, int W, int64_t HW, const int32_t* __restrict__ cam_id,
+                                    const int32_t* __restrict__ pix, int64_t R, const float* __restrict__ images,
+                                    float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ rgb) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int c = cam_id[r], px = pix[r];
+    const float* cam = cams + 16 * (int64_t)c;
+    float pose[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pose[k] = cam[k];
+    float o[3], d[3];
+    pixel_ray(pose, cam[12], cam[13], cam[14], cam[15], W, px, o, d);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rays_o[3 * r + k] = o[k];
+        rays_d[3 * r + k] = d[k];
+    }
+    if (images) {
+        const float* src = images + 3 * ((int64_t)c * HW + px);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rgb[3 * r + k] = src[k];
+    }
+}
+
 // Depth of sample n: src/Camera.py:133-137 (midpoint strata, lower + (upper-lower)*u).
 __device__ __forceinline__ float stratified_depth(const float* __restrict__ z_lin, int N, int n, const float* u,
                                                   int64_t un) {
@@ -338,6 +365,19 @@ extern "C" int nerf_raygen(const float* c2w, float fx, float fy, float cx, float
     hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, c2w, fx, fy,
                        cx, cy, W, pix, R, rays_o, rays_d);
     return check_launch("nerf_raygen");
+}
+
+extern "C" int nerf_raygen_multi(const float* cams, int n_cams, int H, int W, const int32_t* cam_id, const int32_t* pix,
+                                 int64_t R, const float* images, float* rays_o, float* rays_d, float* rgb, void* stream) {
+    if (R == 0) return NERF_OK;
+    NERF_REQUIRE(cams && cam_id && pix && rays_o && rays_d, "nerf_raygen_multi: null pointer");
+    NERF_REQUIRE(n_cams > 0 && H > 0 && W > 0 && R >= 0, "nerf_raygen_multi: bad size n=%d H=%d W=%d R=%lld", n_cams, H, W,
+                 (long long)R);
+    NERF_REQUIRE((int64_t)H * W < (1ll << 31), "nerf_raygen_multi: image too large");
+    NERF_REQUIRE(!images || rgb, "nerf_raygen_multi: images given without an rgb output");
+    hipLaunchKernelGGL(raygen_multi_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, cams, W,
+                       (int64_t)H * W, cam_id, pix, R, images, rays_o, rays_d, rgb);
+    return check_launch("nerf_raygen_multi");
 }
 
 extern "C" int nerf_stratified_sample(const float* rays_o, const float* rays_d, const float* z_lin, const float* u,

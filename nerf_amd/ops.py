@@ -28,6 +28,28 @@ def raygen(c2w: torch.Tensor, fx: float, fy: float, cx: float, cy: float, H: int
     return o, d
 
 
+def raygen_multi(cams: torch.Tensor, H: int, W: int, cam_id: torch.Tensor, pix: torch.Tensor,
+                 images: Optional[torch.Tensor] = None):
+    """Rays of a batch drawn across cameras.  cams [n,16] (3x4 pose rows, fx, fy, cx, cy); ray r is pixel
+    ``pix[r]`` of camera ``cam_id[r]``; with ``images`` [n,H,W,3] the pixels' colours come back as well."""
+    L.need_gpu(cams, cam_id, pix, images)
+    cams = L.f32c(cams)
+    assert cams.dim() == 2 and cams.shape[1] == 16, f"cams must be [n,16], got {tuple(cams.shape)}"
+    cam_id = cam_id.to(torch.int32).contiguous()
+    pix = pix.to(torch.int32).contiguous()
+    R = pix.numel()
+    assert cam_id.numel() == R
+    if images is not None:
+        images = L.f32c(images)
+        assert tuple(images.shape) == (cams.shape[0], H, W, 3), f"images must be [{cams.shape[0]},{H},{W},3]"
+    o = torch.empty(R, 3, device=cams.device, dtype=torch.float32)
+    d = torch.empty_like(o)
+    rgb = torch.empty_like(o) if images is not None else None
+    L.check(L.lib().nerf_raygen_multi(L.ptr(cams), cams.shape[0], H, W, L.ptr(cam_id), L.ptr(pix), R, L.ptr(images),
+                                      L.ptr(o), L.ptr(d), L.ptr(rgb), L.stream_of(cams)), "nerf_raygen_multi")
+    return (o, d, rgb) if images is not None else (o, d)
+
+
 def stratified_sample(rays_o: torch.Tensor, rays_d: torch.Tensor, z_lin: torch.Tensor,
                       u: Optional[torch.Tensor], want_pts: bool = True):
     """rays [R,3], base depths z_lin [N], uniforms u [R,N] or None -> z [R,N], pts [R,N,3]."""

@@ -147,7 +147,7 @@ def _composite_case(dev, tag, wb, g):
     assert float((w.detach().cpu() - T(g[f"{k}_w"])).abs().max()) < 1e-6
     loss = torch.nn.functional.mse_loss(c, T(g[f"{tag}_tgt"]).to(dev)) + 0.05 * (1 - w.sum(dim=-1)).abs().mean()
     loss.backward()
-    assert abs(float(loss) - float(g[f"{k}_loss"])) < 1e-6
+    assert abs(float(loss.detach()) - float(g[f"{k}_loss"])) < 1e-6
     assert torch.allclose(r.grad.cpu(), T(g[f"{k}_drgb"]), rtol=1e-4, atol=1e-8)
     assert torch.allclose(s.grad.cpu(), T(g[f"{k}_dsigma"]), rtol=1e-4, atol=1e-8)
 
