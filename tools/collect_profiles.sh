@@ -21,3 +21,4 @@ run kwrite "bench_kernels.py" WRITE_SIZE
 python3 tools/summarize_pmc.py "$OUT"/mfma/*/*_counter_collection.csv "$OUT"/fetch/*/*_counter_collection.csv "$OUT"/write/*/*_counter_collection.csv > "$OUT/bench_pmc_summary.txt"
 python3 tools/summarize_pmc.py "$OUT"/kfetch/*/*_counter_collection.csv "$OUT"/kwrite/*/*_counter_collection.csv > "$OUT/bench_kernels_pmc_summary.txt"
 ls "$OUT"
+python3 tools/make_traffic_json.py "$OUT" > "$OUT/roofline_traffic.json"
