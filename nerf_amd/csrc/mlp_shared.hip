@@ -462,6 +462,10 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
                                               float* lds) {
     constexpr int NT = 4 * NTW, KTT = KT + KT2, TILES = NT + KTT, J = KTT / GROUP, NM = 6 * NTW * GROUP;
     static_assert(TILES <= 16 && KTT % GROUP == 0, "shape");
+#ifndef NERF_PK_TAIL
+#define NERF_PK_TAIL 6
+#endif
+    constexpr int PTAIL = NERF_PK_TAIL;   // the last 1/PTAIL of a k-step's MFMAs carry no split work
     const int i = lane & 31, s = lane >> 5;
     const int n0 = wave * NTW * 32;
     f32x16 acc[NTW][KTT];
@@ -613,10 +617,12 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
                     constexpr int bi = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
                     acc[nt][k0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[u][nt][ai], bs[par][g][bi], acc[nt][k0 + g], 0, 0, 0);
                     asm volatile("" : "+a"(acc[nt][k0 + g]));
-                    constexpr int step = c * NM + m;   // position within the k-step: its share of the 60 chunks
-                    static_for<(step * 60 + J * NM - 1) / (J * NM), ((step + 1) * 60 + J * NM - 1) / (J * NM)>([&](auto ck) {
-                        chunk(cu, ck, wr, live, p + (u + 4) * 16);
-                    });
+                    // position within the k-step: its share of the 60 chunks, which end PSLOTS MFMAs in so that
+                    // the last stores have landed when the k-step's barrier comes
+                    constexpr int step = c * NM + m, PSLOTS = J * NM - (J * NM) / PTAIL;
+                    constexpr int k_lo = step < PSLOTS ? (step * 60 + PSLOTS - 1) / PSLOTS : 60;
+                    constexpr int k_hi = step + 1 < PSLOTS ? ((step + 1) * 60 + PSLOTS - 1) / PSLOTS : 60;
+                    static_for<k_lo, k_hi>([&](auto ck) { chunk(cu, ck, wr, live, p + (u + 4) * 16); });
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 __builtin_amdgcn_sched_barrier(0);
