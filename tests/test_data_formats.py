@@ -1,4 +1,4 @@
-"""Dataset formats (next-row f4): transforms.json / poses_bounds.npy parsing, unit-sphere normalisation and the
+"""Dataset formats: transforms.json / poses_bounds.npy parsing, unit-sphere normalisation and the
 intrinsics rescaling, checked against independent numpy restatements of the reference's formulas
 (src/data/nerf_capture_dataset.py:20-111, src/data/LLFFDataset.py:24-86).  The reference's own classes need
 torchvision and imageio, which are not installed here, so these results are not pinned by running them:
