@@ -42,8 +42,31 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float b1m, flo
     float* __restrict__ m = t.m[k];
     float* __restrict__ v = t.v[k];
     const bool vec = (((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0;
+    constexpr int ROUNDS = ADAM_CHUNK / (256 * 4);
+    if (vec && base + ADAM_CHUNK <= n) {   // a whole chunk: all requests go out before the first result is used
+        float4 pp[ROUNDS], mm[ROUNDS], vv[ROUNDS], gg[ROUNDS];
 #pragma unroll
-    for (int j = 0; j < ADAM_CHUNK / (256 * 4); ++j) {
+        for (int j = 0; j < ROUNDS; ++j) {
+            const long long i = base + (long long)(j * 256 + threadIdx.x) * 4;
+            pp[j] = *reinterpret_cast<float4*>(p + i);
+            mm[j] = *reinterpret_cast<float4*>(m + i);
+            vv[j] = *reinterpret_cast<float4*>(v + i);
+            gg[j] = *reinterpret_cast<const float4*>(g + i);
+        }
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const long long i = base + (long long)(j * 256 + threadIdx.x) * 4;
+            adam_one(pp[j].x, gg[j].x, mm[j].x, vv[j].x, b1m, b2, b2m, bias2_sqrt, eps, neg_step);
+            adam_one(pp[j].y, gg[j].y, mm[j].y, vv[j].y, b1m, b2, b2m, bias2_sqrt, eps, neg_step);
+            adam_one(pp[j].z, gg[j].z, mm[j].z, vv[j].z, b1m, b2, b2m, bias2_sqrt, eps, neg_step);
+            adam_one(pp[j].w, gg[j].w, mm[j].w, vv[j].w, b1m, b2, b2m, bias2_sqrt, eps, neg_step);
+            *reinterpret_cast<float4*>(p + i) = pp[j];
+            *reinterpret_cast<float4*>(m + i) = mm[j];
+            *reinterpret_cast<float4*>(v + i) = vv[j];
+        }
+        return;
+    }
+    for (int j = 0; j < ROUNDS; ++j) {
         const long long i = base + (long long)(j * 256 + threadIdx.x) * 4;
         if (vec && i + 4 <= n) {
             float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i),
