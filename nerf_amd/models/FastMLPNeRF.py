@@ -7,9 +7,9 @@ from ..utils.positional_encoding import PositionalEncoding
 
 
 class FastMLPNeRF(nn.Module):
-    _skip_h_first = True  # layer-4 input is [h | x_enc]
-
     """Parameter names/shapes/creation order of src/models/FastMLPNeRF.py:7-45."""
+
+    _skip_h_first = True  # layer-4 input is [h | x_enc]
 
     def __init__(self, num_layers=8, hidden_dim=256, skips=[4], num_encoding_fn_xyz=10, num_encoding_fn_dir=4):
         super().__init__()

@@ -7,8 +7,6 @@ from ..utils.positional_encoding import PositionalEncoding
 
 
 class NeRF(nn.Module):
-    _skip_h_first = False  # layer-4 input is [x_enc | h]
-
     """Same constructor, parameter names/shapes/creation order (hence the same
     seeded initial weights and state dict) as src/models/NeRF.py:16-65.
 
@@ -17,6 +15,8 @@ class NeRF(nn.Module):
     every script of the reference instantiates (10/4 frequency bands, 8 layers
     of 256, skip at 4); other hyper-parameters raise NotImplementedError.
     """
+
+    _skip_h_first = False  # layer-4 input is [x_enc | h]
 
     def __init__(self, input_dim=3, xyz_freqs=10, dir_freqs=4, hidden_dim=256, num_layers=8, skips=[4]):
         super().__init__()
