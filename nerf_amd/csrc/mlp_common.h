@@ -348,6 +348,9 @@ __device__ __forceinline__ void x6_prime(WeightStream& ws, const float* c0, int 
 // acc[ot] += W_tile(ot, kt) * in[kt], weights from the stream (three rotating chunk buffers of
 // X6_CHUNK_FLOATS, one barrier per k-step in its middle; see the fp32 dense_shared for the protocol).
 // DRAIN: also write the input tiles to sv.rows0, tile t during k-steps 2t and 2t+1.
+#ifndef NERF_SPREAD_READS
+#define NERF_SPREAD_READS 1
+#endif
 template <int KT, int OT, bool DRAIN = false>
 __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restrict__ wp, const NextChunks nx,
                                          const f32x16 (&in)[KT], f32x16 (&acc)[OT],
@@ -386,12 +389,12 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
             else nl[i] = cvt_pk_bf16(sr0[i], sr1[i]);
         }
     };
+    auto read_one = [&](unsigned rd, auto cg, auto ce, bf16x8 (&o)[12]) {
+        constexpr int g = decltype(cg)::value, e = decltype(ce)::value;
+        o[e] = lds_read_bf8<((4 * g + e / 3) * 3 + e % 3) * 1024>(rd);
+    };
     auto read_group = [&](unsigned rd, auto cg, bf16x8 (&o)[12]) {
-        constexpr int g = decltype(cg)::value;
-        static_for<0, 12>([&](auto ce) {
-            constexpr int e = decltype(ce)::value;
-            o[e] = lds_read_bf8<((4 * g + e / 3) * 3 + e % 3) * 1024>(rd);
-        });
+        static_for<0, 12>([&](auto ce) { read_one(rd, cg, ce, o); });
     };
     split_step(std::integral_constant<int, 0>{}, b);
     {
@@ -451,8 +454,10 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                     }
                 });
             }
+#if !NERF_SPREAD_READS
             if constexpr (g + 1 < G) read_group(rd, std::integral_constant<int, g + 1>{}, nxt);
             else if constexpr (s + 1 < S) read_group(rd_next, std::integral_constant<int, 0>{}, nxt);
+#endif
             if constexpr (g == G - 1) {
                 if constexpr (DRAIN) {
                     constexpr int k0 = 2 * (s % 2);
@@ -468,6 +473,15 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                 constexpr int bs = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
                 acc[4 * g + o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[3 * o + as], b[bs], acc[4 * g + o], 0, 0, 0);
                 asm volatile("" : "+a"(acc[4 * g + o]));
+#if NERF_SPREAD_READS
+                // the next group's operands, one request per MFMA: the four waves run in step, and twelve requests
+                // from each at the same moment queue up in the LDS
+                if constexpr (m <= 12) {
+                    if constexpr (g + 1 < G) read_one(rd, std::integral_constant<int, g + 1>{}, std::integral_constant<int, m - 1>{}, nxt);
+                    else if constexpr (s + 1 < S) read_one(rd_next, std::integral_constant<int, 0>{}, std::integral_constant<int, m - 1>{}, nxt);
+                    if constexpr (s + 1 >= S) __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
                 if constexpr (s + 1 < S) {
                     constexpr int slot = 24 * g + m;
                     static_for<(slot * 11 + 24 * G - 1) / (24 * G), ((slot + 1) * 11 + 24 * G - 1) / (24 * G)>(
