@@ -433,38 +433,15 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                     *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * k0) * sv.ld + 32 * t) = d0;
                     *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * (k0 + 1)) * sv.ld + 32 * t) = d1;
                 }
-                if constexpr (s % 2 == 0) {
-                    static_for<0, 4>([&](auto cq) {
-                        constexpr int q = decltype(cq)::value;
-                        lds_write4<32 * q>(sv.tb.wr, f32x4{in[s / 2][4 * q], in[s / 2][4 * q + 1], in[s / 2][4 * q + 2], in[s / 2][4 * q + 3]});
-                    });
-                }
             }
-            if constexpr (g == G / 2) {   // the middle of the chunk
+            if constexpr (g == G / 2) {   // the middle of the chunk; the copies of chunk s+2 follow among the MFMAs
                 if constexpr (s == 0) ws_ready<0>();
                 else ws_ready<DRAIN ? 2 : 0>();   // DRAIN: the two row stores of this k-step are younger than the copies
-                static_for<0, 6>([&](auto cq) {
-                    constexpr int q = decltype(cq)::value;
-                    if constexpr (s + 2 < S) {
-                        if constexpr (q < PW) ws_copy_piece(ws, wp + (s + 2) * CHF, buf2, q);
-                    } else if constexpr (s + 2 - S == 0) {
-                        if (q < nx.pw0) ws_copy_piece(ws, nx.p0, buf2, q);
-                    } else {
-                        if (q < nx.pw1) ws_copy_piece(ws, nx.p1, buf2, q);
-                    }
-                });
             }
 #if !NERF_SPREAD_READS
             if constexpr (g + 1 < G) read_group(rd, std::integral_constant<int, g + 1>{}, nxt);
             else if constexpr (s + 1 < S) read_group(rd_next, std::integral_constant<int, 0>{}, nxt);
 #endif
-            if constexpr (g == G - 1) {
-                if constexpr (DRAIN) {
-                    constexpr int k0 = 2 * (s % 2);
-                    d0 = lds_read4<8 * k0 * TILE_LD * 4>(sv.tb.rd);
-                    d1 = lds_read4<8 * (k0 + 1) * TILE_LD * 4>(sv.tb.rd);
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
             // the other 23 MFMAs of the group, smallest terms first: l*h, h*l, m*m, m*h, h*m, h*h
             static_for<1, 24>([&](auto cm) {
@@ -474,14 +451,35 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                 acc[4 * g + o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[3 * o + as], b[bs], acc[4 * g + o], 0, 0, 0);
                 asm volatile("" : "+a"(acc[4 * g + o]));
 #if NERF_SPREAD_READS
-                // the next group's operands, one request per MFMA: the four waves run in step, and twelve requests
-                // from each at the same moment queue up in the LDS
+                // One memory request per MFMA: the four waves run in step, and bursts from each of them at the same
+                // moment queue up.  The next group's twelve operands first,
                 if constexpr (m <= 12) {
                     if constexpr (g + 1 < G) read_one(rd, std::integral_constant<int, g + 1>{}, std::integral_constant<int, m - 1>{}, nxt);
                     else if constexpr (s + 1 < S) read_one(rd_next, std::integral_constant<int, 0>{}, std::integral_constant<int, m - 1>{}, nxt);
-                    if constexpr (s + 1 >= S) __builtin_amdgcn_sched_barrier(0);
                 }
 #endif
+                // between them the copies of chunk s+2 (after the barrier of this group),
+                if constexpr (g == G / 2 && m % 2 == 0 && m <= 12) {
+                    constexpr int q = m / 2 - 1;
+                    if constexpr (s + 2 < S) {
+                        if constexpr (q < PW) ws_copy_piece(ws, wp + (s + 2) * CHF, buf2, q);
+                    } else if constexpr (s + 2 - S == 0) {
+                        if (q < nx.pw0) ws_copy_piece(ws, nx.p0, buf2, q);
+                    } else {
+                        if (q < nx.pw1) ws_copy_piece(ws, nx.p1, buf2, q);
+                    }
+                }
+                // then an input tile into the transposition buffer and two of its row blocks back out
+                if constexpr (DRAIN && g == 0 && s % 2 == 0 && m >= 13 && m <= 16) {
+                    constexpr int q = m - 13;
+                    lds_write4<32 * q>(sv.tb.wr, f32x4{in[s / 2][4 * q], in[s / 2][4 * q + 1], in[s / 2][4 * q + 2], in[s / 2][4 * q + 3]});
+                }
+                if constexpr (DRAIN && g == G - 1 && (m == 17 || m == 18)) {
+                    constexpr int k0 = 2 * (s % 2);
+                    if constexpr (m == 17) d0 = lds_read4<8 * k0 * TILE_LD * 4>(sv.tb.rd);
+                    else d1 = lds_read4<8 * (k0 + 1) * TILE_LD * 4>(sv.tb.rd);
+                }
+                if constexpr (s + 1 >= S) __builtin_amdgcn_sched_barrier(0);
                 if constexpr (s + 1 < S) {
                     constexpr int slot = 24 * g + m;
                     static_for<(slot * 11 + 24 * G - 1) / (24 * G), ((slot + 1) * 11 + 24 * G - 1) / (24 * G)>(
