@@ -427,16 +427,11 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                     [&](auto ck) { split_chunk(std::integral_constant<int, s + 1>{}, ck); });
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (DRAIN && g == 0) {
-                if constexpr (s > 0) {   // the two row blocks read during the previous k-step
-                    constexpr int t = (s - 1) / 2, k0 = 2 * ((s - 1) % 2);
-                    *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * k0) * sv.ld + 32 * t) = d0;
-                    *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * (k0 + 1)) * sv.ld + 32 * t) = d1;
-                }
-            }
             if constexpr (g == G / 2) {   // the middle of the chunk; the copies of chunk s+2 follow among the MFMAs
-                if constexpr (s == 0) ws_ready<0>();
-                else ws_ready<DRAIN ? 2 : 0>();   // DRAIN: the two row stores of this k-step are younger than the copies
+                // DRAIN: the two row stores that follow a chunk's copies (MFMAs 13 and 15 of the group after them, or
+                // of the same group when a k-step is one group) are younger than the copies waited for here
+                if constexpr (s == 0 || (G == 1 && s == 1)) ws_ready<0>();
+                else ws_ready<DRAIN ? 2 : 0>();
             }
 #if !NERF_SPREAD_READS
             if constexpr (g + 1 < G) read_group(rd, std::integral_constant<int, g + 1>{}, nxt);
@@ -469,7 +464,13 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                         if (q < nx.pw1) ws_copy_piece(ws, nx.p1, buf2, q);
                     }
                 }
-                // then an input tile into the transposition buffer and two of its row blocks back out
+                // then the two row blocks read during the previous k-step leave for memory,
+                if constexpr (DRAIN && g == 0 && s > 0 && (m == 13 || m == 15)) {
+                    constexpr int t = (s - 1) / 2, k0 = 2 * ((s - 1) % 2);
+                    if constexpr (m == 13) *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * k0) * sv.ld + 32 * t) = d0;
+                    else *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * (k0 + 1)) * sv.ld + 32 * t) = d1;
+                }
+                // an input tile goes into the transposition buffer and two of its row blocks come back out
                 if constexpr (DRAIN && g == 0 && s % 2 == 0 && m >= 13 && m <= 16) {
                     constexpr int q = m - 13;
                     lds_write4<32 * q>(sv.tb.wr, f32x4{in[s / 2][4 * q], in[s / 2][4 * q + 1], in[s / 2][4 * q + 2], in[s / 2][4 * q + 3]});

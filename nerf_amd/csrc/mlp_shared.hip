@@ -461,7 +461,7 @@ template <int NTW, int KT, int KT2, int GROUP>
 __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
                                               float* lds) {
     constexpr int NT = 4 * NTW, KTT = KT + KT2, TILES = NT + KTT, J = KTT / GROUP, NM = 6 * NTW * GROUP;
-    static_assert(TILES <= 16 && KTT % GROUP == 0, "shape");
+    static_assert(TILES <= 16 && KTT % GROUP == 0 && (NTW + GROUP) * 3 <= NM, "shape");
 #ifndef NERF_PK_TAIL
 #define NERF_PK_TAIL 6
 #endif
@@ -556,18 +556,19 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
         }
     };
     bf16x8 as[2][NTW][3], bs[2][GROUP][3];
+    auto read_a1 = [&](unsigned buf, auto ce, bf16x8 (&o)[NTW][3]) {
+        constexpr int e = decltype(ce)::value;
+        o[e / 3][e % 3] = lds_read_bf8<(e / 3) * PK_TILE_BYTES + (e % 3) * 1024>(buf + rd_a_off);
+    };
+    auto read_b1 = [&](unsigned buf, auto cc, auto ce, bf16x8 (&o)[GROUP][3]) {
+        constexpr int k0 = GROUP * decltype(cc)::value, e = decltype(ce)::value;
+        o[e / 3][e % 3] = lds_read_bf8<(NT + k0 + e / 3) * PK_TILE_BYTES + (e % 3) * 1024>(buf + rd_b_off);
+    };
     auto read_a = [&](unsigned buf, bf16x8 (&o)[NTW][3]) {
-        static_for<0, NTW * 3>([&](auto ce) {
-            constexpr int e = decltype(ce)::value;
-            o[e / 3][e % 3] = lds_read_bf8<(e / 3) * PK_TILE_BYTES + (e % 3) * 1024>(buf + rd_a_off);
-        });
+        static_for<0, NTW * 3>([&](auto ce) { read_a1(buf, ce, o); });
     };
     auto read_b = [&](unsigned buf, auto cc, bf16x8 (&o)[GROUP][3]) {
-        constexpr int k0 = GROUP * decltype(cc)::value;
-        static_for<0, GROUP * 3>([&](auto ce) {
-            constexpr int e = decltype(ce)::value;
-            o[e / 3][e % 3] = lds_read_bf8<(NT + k0 + e / 3) * PK_TILE_BYTES + (e % 3) * 1024>(buf + rd_b_off);
-        });
+        static_for<0, GROUP * 3>([&](auto ce) { read_b1(buf, cc, ce, o); });
     };
 
     // prologue: k-steps 0 and 1 into buffers 0 and 1, k-steps 2 and 3 requested
@@ -604,12 +605,6 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
                         for (int e = 0; e < 3; ++e) asm volatile("" : "+v"(as[u][nt][e]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (c + 1 < J) {
-                    read_b(cur, std::integral_constant<int, c + 1>{}, bs[par ^ 1]);
-                } else {   // the next k-step's dY tiles and first item; its buffer was complete a barrier ago
-                    read_a(nxt, as[u ^ 1]);
-                    read_b(nxt, std::integral_constant<int, 0>{}, bs[par ^ 1]);
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, NM>([&](auto cm) {
                     constexpr int m = decltype(cm)::value, term = m / (NTW * GROUP), nt = (m / GROUP) % NTW, g = m % GROUP;
@@ -617,6 +612,16 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
                     constexpr int bi = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
                     acc[nt][k0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[u][nt][ai], bs[par][g][bi], acc[nt][k0 + g], 0, 0, 0);
                     asm volatile("" : "+a"(acc[nt][k0 + g]));
+                    // The next item's operands, one request per MFMA (the four waves run in step: bursts from all of
+                    // them at once queue up in the LDS); after the last item the next k-step's dY tiles and first
+                    // item, whose buffer was complete a barrier ago.
+                    if constexpr (c + 1 < J) {
+                        if constexpr (m < GROUP * 3) read_b1(cur, std::integral_constant<int, c + 1>{}, cm, bs[par ^ 1]);
+                    } else {
+                        if constexpr (m < NTW * 3) read_a1(nxt, cm, as[u ^ 1]);
+                        else if constexpr (m < NTW * 3 + GROUP * 3)
+                            read_b1(nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, m - NTW * 3>{}, bs[par ^ 1]);
+                    }
                     // position within the k-step: its share of the 60 chunks, which end PSLOTS MFMAs in so that
                     // the last stores have landed when the k-step's barrier comes
                     constexpr int step = c * NM + m, PSLOTS = J * NM - (J * NM) / PTAIL;
