@@ -134,9 +134,11 @@ constexpr int MLP_LDS_FLOATS = WS_LDS_FLOATS + 4 * TILE_LDS_FLOATS;   // per wor
 __device__ __forceinline__ int wrap3(int x) { return x >= 3 ? x - 3 : x; }
 
 struct WeightStream {
-    float* lds;   // three chunk buffers shared by the workgroup
-    int g3;       // buffer of the chunk the next dense_shared() starts with
+    float* lds;   // the chunk buffers shared by the workgroup
+    int g3;       // buffer of the chunk the next dense layer starts with
     int wave, lane;
+    const float* next = nullptr;   // bf16 x 6 stream: the next chunk to copy, and where the packed layers end
+    const float* end = nullptr;
 };
 // The two chunks that follow a layer's own in the stream, as 1 KiB pieces per wave (0 = none).
 struct NextChunks {
@@ -306,8 +308,6 @@ __device__ __forceinline__ void dense_shared(WeightStream& ws, const float* __re
 // k-step = 3 KiB per out tile = one chunk of the weight stream.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int X6_CHUNK_FLOATS = 8 * 3 * 256;              // largest chunk: a k-step of 8 out tiles (24 KiB)
-constexpr int X6_LDS_FLOATS = 3 * X6_CHUNK_FLOATS;
-constexpr int X6_MLP_LDS_FLOATS = X6_LDS_FLOATS + 4 * TILE_LDS_FLOATS;
 constexpr int x6_layer_floats(int KT, int OT) { return 2 * KT * OT * 3 * 256; }
 
 __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
@@ -334,29 +334,50 @@ __device__ __forceinline__ bf16x8 lds_read_bf8(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF_BYTES));
     return r;
 }
-template <int OT_NEXT>
-__device__ __forceinline__ NextChunks next_chunks_x6(const float* after) {
-    constexpr int CHF = OT_NEXT * 3 * 256;
-    return NextChunks{after, CHF / 1024, after + CHF, CHF / 1024};
+// The weight stream of the bf16 x 6 layers.  The packed layers of a kernel lie in memory in the order they are
+// used and every chunk is 24 KiB (a k-step of 8 out tiles, or two k-steps of 4), so the stream is one linear
+// run of chunks through four rotating LDS buffers: while chunk c is multiplied, chunk c+1 has landed, chunk
+// c+2 is on its way and the copies of chunk c+3 go out (in the middle of chunk c, after the barrier that frees
+// the buffer of chunk c-1).  The wait for chunk c+1 in the middle of chunk c so concerns copies issued two
+// chunks earlier: vector memory operations complete in issue order, and with a ring of three that wait also
+// covered the row stores of the previous k-step, whose acknowledgement takes longer than a k-step.
+// Past the end of the stream the last chunk is copied again, so that the count of operations in flight
+// stays what the waits assume.
+constexpr int X6_RING = 4;
+constexpr int X6_LDS_FLOATS = X6_RING * X6_CHUNK_FLOATS;
+constexpr int X6_PIECES = X6_CHUNK_FLOATS / 1024;   // 1 KiB pieces per wave per chunk
+__device__ __forceinline__ const float* x6_next_chunk(const WeightStream& ws) {
+    return ws.next < ws.end ? ws.next : ws.end - X6_CHUNK_FLOATS;
 }
-__device__ __forceinline__ void x6_prime(WeightStream& ws, const float* c0, int pw0, const float* c1, int pw1) {
-    for (int q = 0; q < pw0; ++q) ws_copy_piece(ws, c0, ws.lds, q);
-    for (int q = 0; q < pw1; ++q) ws_copy_piece(ws, c1, ws.lds + X6_CHUNK_FLOATS, q);
+__device__ __forceinline__ void x6_copy_chunk(WeightStream& ws, int buf) {
+    const float* src = x6_next_chunk(ws);
+#pragma unroll
+    for (int q = 0; q < X6_PIECES; ++q) ws_copy_piece(ws, src, ws.lds + buf * X6_CHUNK_FLOATS, q);
+    ws.next += X6_CHUNK_FLOATS;
+}
+// Start the stream at `first`: request its first three chunks.  ws_ready() must follow before the first dense_x6().
+__device__ __forceinline__ void x6_prime(WeightStream& ws, const float* first, const float* end) {
+    ws.next = first;
+    ws.end = end;
+    x6_copy_chunk(ws, 0);
+    x6_copy_chunk(ws, 1);
+    x6_copy_chunk(ws, 2);
     ws.g3 = 0;
 }
 
-// acc[ot] += W_tile(ot, kt) * in[kt], weights from the stream (three rotating chunk buffers of
-// X6_CHUNK_FLOATS, one barrier per k-step in its middle; see the fp32 dense_shared for the protocol).
+// Row stores a layer issues in its k-step k (none in k-step 0, and nothing is assumed about the previous layer).
+template <bool DRAIN>
+constexpr int x6_stores(int k) { return DRAIN && k > 0 ? 2 : 0; }
+
+// acc[ot] += W_tile(ot, kt) * in[kt], the layer's weights being the next KT * OT / 4 chunks of the stream.
+// A chunk is two groups of 24 MFMAs (4 out tiles x 6 terms): the two halves of a k-step (OT = 8) or two
+// k-steps (OT = 4); one barrier per chunk, between its groups.
 // DRAIN: also write the input tiles to sv.rows0, tile t during k-steps 2t and 2t+1.
-#ifndef NERF_SPREAD_READS
-#define NERF_SPREAD_READS 1
-#endif
 template <int KT, int OT, bool DRAIN = false>
-__device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restrict__ wp, const NextChunks nx,
-                                         const f32x16 (&in)[KT], f32x16 (&acc)[OT],
+__device__ __forceinline__ void dense_x6(WeightStream& ws, const f32x16 (&in)[KT], f32x16 (&acc)[OT],
                                          TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
-    static_assert(OT % 4 == 0, "out tiles are processed four at a time");
-    constexpr int S = 2 * KT, G = OT / 4, CHF = OT * 3 * 256, PW = CHF / 1024;
+    static_assert(OT == 4 || OT == 8, "out tiles are processed four at a time, two groups per chunk");
+    constexpr int S = 2 * KT, G = OT / 4, NCH = S * G / 2;
     bf16x8 a[2][12];                 // operands of a group of 4 out tiles (tile*3 + split), double-buffered
     bf16x8 b[3];                     // this k-step's B splits (h, m, l); the next one's are built in nh, nm, nl
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};   // two row blocks on their way out
@@ -389,7 +410,7 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
             else nl[i] = cvt_pk_bf16(sr0[i], sr1[i]);
         }
     };
-    auto read_one = [&](unsigned rd, auto cg, auto ce, bf16x8 (&o)[12]) {
+    auto read_one = [&](unsigned rd, auto cg, auto ce, bf16x8 (&o)[12]) {   // group 0 or 1 of the chunk at rd
         constexpr int g = decltype(cg)::value, e = decltype(ce)::value;
         o[e] = lds_read_bf8<((4 * g + e / 3) * 3 + e % 3) * 1024>(rd);
     };
@@ -403,13 +424,13 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
     }
     static_for<0, S>([&](auto cs) {
         constexpr int s = decltype(cs)::value;
-        const int b0 = wrap3(ws.g3 + s % 3);
-        const unsigned rd = lds_addr(ws.lds + b0 * X6_CHUNK_FLOATS) + ws.lane * 16;
-        const unsigned rd_next = lds_addr(ws.lds + wrap3(b0 + 1) * X6_CHUNK_FLOATS) + ws.lane * 16;
-        float* buf2 = ws.lds + wrap3(b0 + 2) * X6_CHUNK_FLOATS;
         static_for<0, G>([&](auto cg) {
             constexpr int g = decltype(cg)::value;
-            constexpr int par = (s * G + g) % 2;
+            constexpr int q = s * G + g, ch = q / 2, gg = q % 2;   // group q of the layer: half gg of its chunk ch
+            constexpr int par = q % 2;
+            const int b0 = (ws.g3 + ch) & 3;
+            const unsigned rd = lds_addr(ws.lds + b0 * X6_CHUNK_FLOATS) + ws.lane * 16;
+            const unsigned rd_next = lds_addr(ws.lds + ((b0 + 1) & 3) * X6_CHUNK_FLOATS) + ws.lane * 16;
             bf16x8(&cur)[12] = a[par];
             bf16x8(&nxt)[12] = a[par ^ 1];
             lgkm_wait();
@@ -427,16 +448,19 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                     [&](auto ck) { split_chunk(std::integral_constant<int, s + 1>{}, ck); });
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (g == G / 2) {   // the middle of the chunk; the copies of chunk s+2 follow among the MFMAs
-                // DRAIN: the two row stores that follow a chunk's copies (MFMAs 13 and 15 of the group after them, or
-                // of the same group when a k-step is one group) are younger than the copies waited for here
-                if constexpr (s == 0 || (G == 1 && s == 1)) ws_ready<0>();
-                else ws_ready<DRAIN ? 2 : 0>();
+            const float* copy_src = nullptr;
+            if constexpr (gg == 1) {   // the middle of the chunk: chunk ch+1 must have landed
+                // Vector memory operations this wave has certainly issued after the copies of chunk ch+1 (two
+                // chunks ago) may stay in flight: the copies of chunk ch+2 and the row stores since, which follow
+                // their k-step's copies (MFMAs 13 and 15).  This layer's k-step 0 has no stores; at the start of a
+                // layer only the previous layer's copies are counted.
+                constexpr int YOUNGER = X6_PIECES + (ch == 0 ? 0 : G == 2 ? x6_stores<DRAIN>(ch - 1) + x6_stores<DRAIN>(ch)
+                                                                   : x6_stores<DRAIN>(2 * ch - 3) + x6_stores<DRAIN>(2 * ch - 2) +
+                                                                     x6_stores<DRAIN>(2 * ch - 1) + x6_stores<DRAIN>(2 * ch));
+                ws_ready<YOUNGER>();
+                copy_src = x6_next_chunk(ws);
+                ws.next += X6_CHUNK_FLOATS;
             }
-#if !NERF_SPREAD_READS
-            if constexpr (g + 1 < G) read_group(rd, std::integral_constant<int, g + 1>{}, nxt);
-            else if constexpr (s + 1 < S) read_group(rd_next, std::integral_constant<int, 0>{}, nxt);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             // the other 23 MFMAs of the group, smallest terms first: l*h, h*l, m*m, m*h, h*m, h*h
             static_for<1, 24>([&](auto cm) {
@@ -445,25 +469,15 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                 constexpr int bs = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
                 acc[4 * g + o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[3 * o + as], b[bs], acc[4 * g + o], 0, 0, 0);
                 asm volatile("" : "+a"(acc[4 * g + o]));
-#if NERF_SPREAD_READS
                 // One memory request per MFMA: the four waves run in step, and bursts from each of them at the same
                 // moment queue up.  The next group's twelve operands first,
                 if constexpr (m <= 12) {
-                    if constexpr (g + 1 < G) read_one(rd, std::integral_constant<int, g + 1>{}, std::integral_constant<int, m - 1>{}, nxt);
-                    else if constexpr (s + 1 < S) read_one(rd_next, std::integral_constant<int, 0>{}, std::integral_constant<int, m - 1>{}, nxt);
+                    if constexpr (gg == 0) read_one(rd, std::integral_constant<int, 1>{}, std::integral_constant<int, m - 1>{}, nxt);
+                    else if constexpr (q + 1 < S * G) read_one(rd_next, std::integral_constant<int, 0>{}, std::integral_constant<int, m - 1>{}, nxt);
                 }
-#endif
-                // between them the copies of chunk s+2 (after the barrier of this group),
-                if constexpr (g == G / 2 && m % 2 == 0 && m <= 12) {
-                    constexpr int q = m / 2 - 1;
-                    if constexpr (s + 2 < S) {
-                        if constexpr (q < PW) ws_copy_piece(ws, wp + (s + 2) * CHF, buf2, q);
-                    } else if constexpr (s + 2 - S == 0) {
-                        if (q < nx.pw0) ws_copy_piece(ws, nx.p0, buf2, q);
-                    } else {
-                        if (q < nx.pw1) ws_copy_piece(ws, nx.p1, buf2, q);
-                    }
-                }
+                // between them the copies of chunk ch+3 (after the barrier of this group),
+                if constexpr (gg == 1 && m % 2 == 0 && m <= 12)
+                    ws_copy_piece(ws, copy_src, ws.lds + ((b0 + 3) & 3) * X6_CHUNK_FLOATS, m / 2 - 1);
                 // then the two row blocks read during the previous k-step leave for memory,
                 if constexpr (DRAIN && g == 0 && s > 0 && (m == 13 || m == 15)) {
                     constexpr int t = (s - 1) / 2, k0 = 2 * ((s - 1) % 2);
@@ -472,8 +486,8 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
                 }
                 // an input tile goes into the transposition buffer and two of its row blocks come back out
                 if constexpr (DRAIN && g == 0 && s % 2 == 0 && m >= 13 && m <= 16) {
-                    constexpr int q = m - 13;
-                    lds_write4<32 * q>(sv.tb.wr, f32x4{in[s / 2][4 * q], in[s / 2][4 * q + 1], in[s / 2][4 * q + 2], in[s / 2][4 * q + 3]});
+                    constexpr int qq = m - 13;
+                    lds_write4<32 * qq>(sv.tb.wr, f32x4{in[s / 2][4 * qq], in[s / 2][4 * qq + 1], in[s / 2][4 * qq + 2], in[s / 2][4 * qq + 3]});
                 }
                 if constexpr (DRAIN && g == G - 1 && (m == 17 || m == 18)) {
                     constexpr int k0 = 2 * (s % 2);
@@ -504,7 +518,7 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const float* __restri
         *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)16 * sv.ld + 32 * t) = d0;
         *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)24 * sv.ld + 32 * t) = d1;
     }
-    ws.g3 = wrap3(ws.g3 + S % 3);
+    ws.g3 = (ws.g3 + NCH) & 3;
 }
 
 // acc tiles <- per-neuron vector v[32*t + rowmap(r,h)] (bias as the initial accumulator).

@@ -90,23 +90,23 @@ template <int KT, int OT, bool DRAIN = false>
 __device__ __forceinline__ void dense_layer(WeightStream& ws, const float* __restrict__ wp, const NextChunks nx,
                                             const f32x16 (&in)[KT], f32x16 (&acc)[OT],
                                             TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
-    if constexpr (MLP_X6) dense_x6<KT, OT, DRAIN>(ws, wp, nx, in, acc, sv);
+    if constexpr (MLP_X6) dense_x6<KT, OT, DRAIN>(ws, in, acc, sv);   // the stream knows what comes next
     else dense_shared<KT, OT, DRAIN>(ws, wp, nx, in, acc, sv);
 }
 template <int OT_NEXT>
 __device__ __forceinline__ NextChunks chunks_after(const float* after) {
-    if constexpr (MLP_X6) return next_chunks_x6<OT_NEXT>(after);
+    if constexpr (MLP_X6) return NO_CHUNKS;
     else return next_chunks<OT_NEXT>(after);
 }
-__device__ __forceinline__ void stream_prime(WeightStream& ws, const float* first) {   // a layer of 8 out tiles
-    if constexpr (MLP_X6) x6_prime(ws, first, 6, first + X6_CHUNK_FLOATS, 6);
+__device__ __forceinline__ void stream_prime(WeightStream& ws, const float* first, const float* end) {   // a layer of 8 out tiles
+    if constexpr (MLP_X6) x6_prime(ws, first, end);
     else ws_prime(ws, first, 8, first + WS_CHUNK_FLOATS, 8);
 }
 constexpr int STREAM_LDS_FLOATS = MLP_X6 ? X6_LDS_FLOATS : WS_LDS_FLOATS;
 constexpr int KERNEL_LDS_FLOATS = STREAM_LDS_FLOATS + 4 * TILE_LDS_FLOATS;
 // The chunks of the view-direction layer (1 in-tile, 4 out tiles): two k-steps of 12 KiB, or one chunk of 16 KiB.
 __device__ __forceinline__ NextChunks dir_chunks(const float* first) {
-    if constexpr (MLP_X6) return next_chunks_x6<4>(first);
+    if constexpr (MLP_X6) return NO_CHUNKS;
     else return NextChunks{first, 4, nullptr, 0};
 }
 
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     WeightStream wst{lds, 0, ix.wave, lane};
     const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
     // the weight stream runs through the packed layers in the order they are used
-    stream_prime(wst, pk + vp::F_L0);
+    stream_prime(wst, pk + vp::F_L0, pk + vp::B_RGB0);
     const float x0 = x[3 * ix.lp], x1 = x[3 * ix.lp + 1], x2 = x[3 * ix.lp + 2];
     uint4* mask_out = SAVE ? reinterpret_cast<uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane : nullptr;
 
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
     const int lane = ix.lane, h = ix.h;
     WeightStream wst{lds, 0, ix.wave, lane};
     const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
-    stream_prime(wst, pk + vp::B_RGB0);
+    stream_prime(wst, pk + vp::B_RGB0, pk + vp::S_BIAS);
     const uint4* mask_in = reinterpret_cast<const uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane;
     float dpre[3], dps = 0.0f;
 #pragma unroll
