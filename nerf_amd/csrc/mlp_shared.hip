@@ -449,6 +449,7 @@ __device__ __forceinline__ void wgrad_part_x6(const WgradPart& pt, long long p_b
 // A tile's stride is padded by 16 bytes so that the four tiles a wave stores at once fall on different banks.
 constexpr int PK_TILE_BYTES = 3 * 1024 + 16;
 constexpr int PK_BUF_BYTES = 16 * PK_TILE_BYTES;
+constexpr int PK_CHUNKS = 68;   // steps of the operand split of a k-step (see wgrad_part_pk)
 static_assert(3 * PK_BUF_BYTES <= WG_LDS_FLOATS * 4, "operand buffers exceed the LDS allocation");
 
 template <int OFF_BYTES>
@@ -505,11 +506,11 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
         R[decltype(cu)::value][decltype(cq)::value] = *reinterpret_cast<const float4*>(src + (pc + decltype(cq)::value) * ld);
     };
     auto load_raw = [&](auto cu, long long p) { static_for<0, 8>([&](auto cq) { load_row(cu, cq, p); }); };
-    // Splitting a k-step is 60 chunks of at most six mutually independent instructions, one chunk per MFMA:
+    // Splitting a k-step is 68 chunks of at most six mutually independent instructions, one chunk per MFMA:
     // a dependent instruction issued right behind its producer waits ~9 clocks and holds up the MFMA queued
     // behind it, whereas up to six independent ones issue under an MFMA for free.  Chunk 14e + 7g + level
     // is one level of the split of rows 2e, 2e+1 of columns 2g, 2g+1 (bf16 pair h, its residual, pair m, its
-    // residual, pair l); chunks 56-59 store the four finished columns.  After the last chunk of a row pair its
+    // residual, pair l); chunks 56-67 store the three operands of the four finished columns.  After the last chunk of a row pair its
     // rows of the k-step after next are requested, so the requests spread over the k-step.
     unsigned PH[4][4], PM[4][4], PL[4][4];   // [column][row pair], two bf16 each
     float t_r0[2], t_r1[2], t_f0[2], t_f1[2], t_sum[2];
@@ -548,11 +549,11 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
                 load_row(cu, std::integral_constant<int, 2 * e>{}, p_next);
                 load_row(cu, std::integral_constant<int, 2 * e + 1>{}, p_next);
             }
-        } else {
-            constexpr int c = k - 56;
-            lds_write_u4<c * 16>(wr, u32x4{PH[c][0], PH[c][1], PH[c][2], PH[c][3]});
-            lds_write_u4<c * 16 + 1024>(wr, u32x4{PM[c][0], PM[c][1], PM[c][2], PM[c][3]});
-            lds_write_u4<c * 16 + 2048>(wr, u32x4{PL[c][0], PL[c][1], PL[c][2], PL[c][3]});
+        } else {   // one store per chunk: the four waves are in step and their stores would arrive together
+            constexpr int c = (k - 56) / 3, part = (k - 56) % 3;
+            if constexpr (part == 0) lds_write_u4<c * 16>(wr, u32x4{PH[c][0], PH[c][1], PH[c][2], PH[c][3]});
+            else if constexpr (part == 1) lds_write_u4<c * 16 + 1024>(wr, u32x4{PM[c][0], PM[c][1], PM[c][2], PM[c][3]});
+            else lds_write_u4<c * 16 + 2048>(wr, u32x4{PL[c][0], PL[c][1], PL[c][2], PL[c][3]});
         }
     };
     bf16x8 as[2][NTW][3], bs[2][GROUP][3];
@@ -574,8 +575,8 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
     // prologue: k-steps 0 and 1 into buffers 0 and 1, k-steps 2 and 3 requested
     load_raw(std::integral_constant<int, 0>{}, p_begin);
     load_raw(std::integral_constant<int, 1>{}, p_begin + 16);
-    static_for<0, 60>([&](auto ck) { chunk(std::integral_constant<int, 0>{}, ck, lds0 + wr_off, 1.0f, p_begin + 32); });
-    static_for<0, 60>([&](auto ck) {
+    static_for<0, PK_CHUNKS>([&](auto ck) { chunk(std::integral_constant<int, 0>{}, ck, lds0 + wr_off, 1.0f, p_begin + 32); });
+    static_for<0, PK_CHUNKS>([&](auto ck) {
         chunk(std::integral_constant<int, 1>{}, ck, lds0 + PK_BUF_BYTES + wr_off, 1.0f, p_begin + 48);
     });
     lgkm_wait();
@@ -622,11 +623,11 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
                         else if constexpr (m < NTW * 3 + GROUP * 3)
                             read_b1(nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, m - NTW * 3>{}, bs[par ^ 1]);
                     }
-                    // position within the k-step: its share of the 60 chunks, which end PSLOTS MFMAs in so that
+                    // position within the k-step: its share of the chunks, which end PSLOTS MFMAs in so that
                     // the last stores have landed when the k-step's barrier comes
                     constexpr int step = c * NM + m, PSLOTS = J * NM - (J * NM) / PTAIL;
-                    constexpr int k_lo = step < PSLOTS ? (step * 60 + PSLOTS - 1) / PSLOTS : 60;
-                    constexpr int k_hi = step + 1 < PSLOTS ? ((step + 1) * 60 + PSLOTS - 1) / PSLOTS : 60;
+                    constexpr int k_lo = step < PSLOTS ? (step * PK_CHUNKS + PSLOTS - 1) / PSLOTS : PK_CHUNKS;
+                    constexpr int k_hi = step + 1 < PSLOTS ? ((step + 1) * PK_CHUNKS + PSLOTS - 1) / PSLOTS : PK_CHUNKS;
                     static_for<k_lo, k_hi>([&](auto ck) { chunk(cu, ck, wr, live, p + (u + 4) * 16); });
                     __builtin_amdgcn_sched_barrier(0);
                 });
