@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
 
 // Relative time per point of a workgroup of each shape (measured for the first three; the
 // narrow shapes run below their MFMA count): the cost model of the slab split.
-static const int kShapeCost[6] = {32, 25, 15, 8, 8, 8};
+static const int kShapeCost[6] = {32, 24, 17, 8, 8, 8};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     // A workgroup takes a whole CU (512 registers per lane), so the grid is sized
