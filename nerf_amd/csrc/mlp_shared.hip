@@ -478,7 +478,9 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
             for (int r = 0; r < 16; ++r) acc[nt][kt][r] = 0.0f;
 
     // producer role: columns 4pj .. 4pj+3 of tile T (dY tiles first, then X, then X2), points 8ps .. 8ps+7 of a k-step
-    const int pj = (lane & 3) | ((lane >> 2) & 4), ptl = (lane >> 2) & 3, ps = lane >> 5;
+    // lane bits: 0 = column quad bit 0, 1-2 = tile, 3-4 = column quad bits 1-2, 5 = point half: any eight (and
+    // sixteen) consecutive lanes store to different banks (tile stride = 193 x 16 B, column quad = 4 x 16 B)
+    const int pj = (lane & 1) | ((lane >> 2) & 6), ptl = (lane >> 1) & 3, ps = lane >> 5;
     const int T = 4 * wave + ptl;
     const bool active = T < TILES;
     const float* src = pt.dY + 4 * pj;   // lanes without a tile load (and store) something harmless
