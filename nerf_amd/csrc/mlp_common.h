@@ -521,6 +521,34 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const f32x16 (&in)[KT
     ws.g3 = (ws.g3 + NCH) & 3;
 }
 
+// dot_rows() below with the vector in LDS (byte address v_lds): a vector-memory load at that point would wait
+// for every weight copy in flight.  Half of the tiles per round trip.
+template <int NT>
+__device__ __forceinline__ float dot_rows_lds(const f32x16 (&a)[NT], unsigned v_lds, int h) {
+    static_assert(NT % 2 == 0, "two halves");
+    const unsigned a0 = v_lds + 16 * h;
+    float s = 0.0f;
+    static_for<0, 2>([&](auto chalf) {
+        constexpr int t0 = decltype(chalf)::value * (NT / 2);
+        f32x4 w[NT / 2][4];
+        static_for<0, NT / 2>([&](auto ct) {
+            static_for<0, 4>([&](auto cq) {
+                w[ct][cq] = lds_read4<(32 * (t0 + decltype(ct)::value) + 8 * decltype(cq)::value) * 4>(a0);
+            });
+        });
+        lgkm_wait();
+#pragma unroll
+        for (int t = 0; t < NT / 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                asm volatile("" : "+v"(w[t][q]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = fmaf(a[t0 + t][4 * q + e], w[t][q][e], s);
+            }
+    });
+    return s + __shfl_xor(s, 32, 64);
+}
+
 // acc tiles <- per-neuron vector v[32*t + rowmap(r,h)] (bias as the initial accumulator).
 template <int NT>
 __device__ __forceinline__ void fill_rows(f32x16 (&acc)[NT], const float* __restrict__ v, int h) {

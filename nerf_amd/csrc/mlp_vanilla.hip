@@ -41,7 +41,9 @@ constexpr int S_WS = S_B1 + 128;
 constexpr int S_BS = S_WS + 256;
 constexpr int S_W2 = S_BS + 4;
 constexpr int S_B2 = S_W2 + 3 * 128;
-constexpr int TOTAL = S_B2 + 4;
+constexpr int HEAD_FLOATS = 3 * 256;         // the head weights from S_WS on, padded to whole 1 KiB pieces: the forward
+constexpr int TOTAL = S_WS + HEAD_FLOATS;    // kernel keeps a copy in LDS
+static_assert(S_B2 + 4 <= TOTAL, "head-weight block");
 }  // namespace vp
 
 namespace vw {  // workspace layout, floats per point (multiply by P32 for the section offset)
@@ -103,7 +105,8 @@ __device__ __forceinline__ void stream_prime(WeightStream& ws, const float* firs
     else ws_prime(ws, first, 8, first + WS_CHUNK_FLOATS, 8);
 }
 constexpr int STREAM_LDS_FLOATS = MLP_X6 ? X6_LDS_FLOATS : WS_LDS_FLOATS;
-constexpr int KERNEL_LDS_FLOATS = STREAM_LDS_FLOATS + 4 * TILE_LDS_FLOATS;
+constexpr int HEAD_LDS_OFF = STREAM_LDS_FLOATS + 4 * TILE_LDS_FLOATS;
+constexpr int KERNEL_LDS_FLOATS = HEAD_LDS_OFF + vp::HEAD_FLOATS;
 // The chunks of the view-direction layer (1 in-tile, 4 out tiles): two k-steps of 12 KiB, or one chunk of 16 KiB.
 __device__ __forceinline__ NextChunks dir_chunks(const float* first) {
     if constexpr (MLP_X6) return NO_CHUNKS;
@@ -122,6 +125,9 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     WeightStream wst{lds, 0, ix.wave, lane};
     const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
     // the weight stream runs through the packed layers in the order they are used
+    // the head weights (density row, rgb rows) go to LDS with the first chunks; complete after ws_ready()
+    if (ix.wave < vp::HEAD_FLOATS / 256) ws_copy_piece(WeightStream{lds, 0, ix.wave, lane}, pk + vp::S_WS, lds + HEAD_LDS_OFF, 0);
+    const unsigned heads = lds_addr(lds + HEAD_LDS_OFF);
     stream_prime(wst, pk + vp::F_L0, pk + vp::B_RGB0);
     const float x0 = x[3 * ix.lp], x1 = x[3 * ix.lp + 1], x2 = x[3 * ix.lp + 2];
     uint4* mask_out = SAVE ? reinterpret_cast<uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane : nullptr;
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
         finish_layer(l);
     }
     // density head: softplus(w.h + b)   (NeRF.py:90)
-    const float sp = dot_rows<8>(hc, pk + vp::S_WS, h) + pk[vp::S_BS];
+    const float sp = dot_rows_lds<8>(hc, heads, h) + pk[vp::S_BS];
     if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(sp);
     // feature layer (no activation)      (NeRF.py:95)
     fill_rows<8>(acc, pk + vp::S_BF, h);
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float v = dot_rows<4>(hr, pk + vp::S_W2 + 128 * c, h) + pk[vp::S_B2 + c];
+        const float v = dot_rows_lds<4>(hr, heads + 4 * (vp::S_W2 - vp::S_WS + 128 * c), h) + pk[vp::S_B2 + c];
         if (ix.valid && h == 0) rgb[3 * ix.gp + c] = sigmoid_f(v);
     }
 }
