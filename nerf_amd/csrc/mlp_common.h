@@ -191,7 +191,7 @@ __device__ __forceinline__ void save_tiles(const TileBuf& tb, float* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             asm volatile("" : "+v"(v[k]));
-            *reinterpret_cast<f32x4*>(rows0 + (size_t)(8 * k + tb.row) * ld + 32 * t + tb.col) = v[k];
+            __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(rows0 + (size_t)(8 * k + tb.row) * ld + 32 * t + tb.col));
         }
     }
 }
@@ -478,11 +478,12 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const f32x16 (&in)[KT
                 // between them the copies of chunk ch+3 (after the barrier of this group),
                 if constexpr (gg == 1 && m % 2 == 0 && m <= 12)
                     ws_copy_piece(ws, copy_src, ws.lds + ((b0 + 3) & 3) * X6_CHUNK_FLOATS, m / 2 - 1);
-                // then the two row blocks read during the previous k-step leave for memory,
+                // then the two row blocks read during the previous k-step leave for memory (non-temporal: they are
+                // read again only by another kernel, after gigabytes of other traffic),
                 if constexpr (DRAIN && g == 0 && s > 0 && (m == 13 || m == 15)) {
                     constexpr int t = (s - 1) / 2, k0 = 2 * ((s - 1) % 2);
-                    if constexpr (m == 13) *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * k0) * sv.ld + 32 * t) = d0;
-                    else *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * (k0 + 1)) * sv.ld + 32 * t) = d1;
+                    if constexpr (m == 13) __builtin_nontemporal_store(d0, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * k0) * sv.ld + 32 * t));
+                    else __builtin_nontemporal_store(d1, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * (k0 + 1)) * sv.ld + 32 * t));
                 }
                 // an input tile goes into the transposition buffer and two of its row blocks come back out
                 if constexpr (DRAIN && g == 0 && s % 2 == 0 && m >= 13 && m <= 16) {
@@ -515,8 +516,8 @@ __device__ __forceinline__ void dense_x6(WeightStream& ws, const f32x16 (&in)[KT
         asm volatile("" : "+v"(d0));
         asm volatile("" : "+v"(d1));
         constexpr int t = (S - 1) / 2;
-        *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)16 * sv.ld + 32 * t) = d0;
-        *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)24 * sv.ld + 32 * t) = d1;
+        __builtin_nontemporal_store(d0, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)16 * sv.ld + 32 * t));
+        __builtin_nontemporal_store(d1, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)24 * sv.ld + 32 * t));
     }
     ws.g3 = (ws.g3 + NCH) & 3;
 }

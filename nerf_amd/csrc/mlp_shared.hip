@@ -505,7 +505,8 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
     // past the end the last k-step is read again and ignored.
     auto load_row = [&](auto cu, auto cq, long long p) {
         const long long pc = p < p_end ? p : p_end - 16;
-        R[decltype(cu)::value][decltype(cq)::value] = *reinterpret_cast<const float4*>(src + (pc + decltype(cq)::value) * ld);
+        const f32x4 ld4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (pc + decltype(cq)::value) * ld));
+        R[decltype(cu)::value][decltype(cq)::value] = make_float4(ld4[0], ld4[1], ld4[2], ld4[3]);
     };
     auto load_raw = [&](auto cu, long long p) { static_for<0, 8>([&](auto cq) { load_row(cu, cq, p); }); };
     // Splitting a k-step is 68 chunks of at most six mutually independent instructions, one chunk per MFMA:
