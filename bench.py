@@ -5,10 +5,12 @@ samples, vanilla 8x256 MLPs (coarse and fine), fp32.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by torch.distributed.run, one rank per GPU: every rank
-renders its own 4096-ray batch (rays are independent, weak scaling) and the
-parameter gradients are averaged with one RCCL all-reduce per step.
-Rank 0 prints ONE JSON line.
+One GPU: the 4096-ray batch the metric is quoted on.  N > 1 is launched by
+torch.distributed.run, one rank per GPU: every rank renders its own 65,536-ray
+batch in ray chunks (rays are independent, weak scaling) and the parameter
+gradients are summed with one RCCL all-reduce per model, issued under the last
+chunk's backward.  Rank 0 prints ONE JSON line; the hash-grid configuration
+rides along in it as "secondary".
 """
 import argparse
 import json
@@ -60,15 +62,88 @@ def make_batch(rank: int, rays: int, dev):
 
 
 NGP_NEAR, NGP_FAR = 0.05, 1.2   # src/train_nerf_ngp.py:32-33 (unit-sphere-normalised poses)
+RAYS_SINGLE, RAYS_DP = 4096, 65536
+NGP_WORKLOAD = ("Instant-NGP variant (16 levels, 2^19 rows, 64-wide MLPs), 800x800 camera on the unit sphere, 64 samples, "
+                "%d-ray batch per GPU, one training step incl. Adam over the tables")
+
+
+def ngp_loss(out, gt):
+    """MSE plus the weight regulariser of src/train_nerf_ngp.py:221-222."""
+    return torch.nn.functional.mse_loss(out["rgb"], gt) + 0.05 * (1.0 - out["weights"].sum(dim=-1)).abs().mean()
+
+
+def build_step(kind, rank, rays, dev, chunk_rays):
+    """One training step of the vanilla (coarse + fine 8x256 MLPs, 64 + 128 samples) or hash-grid workload:
+    fused ray generation + stratified sampling, chunked forward/backward with the gradients in flat buckets
+    (their cross-rank sum starts under the last chunk's backward), fused Adam.  Returns (step, model)."""
+    from nerf_amd import ops
+    from nerf_amd.dist import GradBuckets
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.render import nerf_loss, train_step
+
+    c2w, pix, u_c, u_f, gt = make_batch(rank, rays, dev)
+    if kind == "ngp":
+        # the hash-grid variant: 64 samples, one model, the loss and optimiser settings of
+        # src/train_nerf_ngp.py:221-222 and :55; camera on the unit sphere, near/far of :32-33
+        from nerf_amd.models.FastNGPNeRF import FastNGPNeRF
+        torch.manual_seed(0)
+        model = FastNGPNeRF().to(dev)
+        buckets = GradBuckets([list(model.hash_encoder.parameters()),
+                               [p for n, p in model.named_parameters() if not n.startswith("hash_encoder")]])
+        opt = FusedAdam(buckets.parameters(), lr=1e-2, eps=1e-15)
+        c2w = c2w.clone()
+        c2w[:, 3] = c2w[:, 3] / 4.03
+        z_lin = torch.linspace(NGP_NEAR, NGP_FAR, N_COARSE).to(dev)
+        kw = dict(loss_fn=ngp_loss, white_bkgd=False)
+        near, far = NGP_NEAR, NGP_FAR
+    else:
+        from nerf_amd.models.NeRF import NeRF
+        torch.manual_seed(0)
+        model = NeRF().to(dev)
+        torch.manual_seed(1)
+        fine = NeRF().to(dev)
+        # backward reaches the fine model first: its bucket's all-reduce runs under the coarse model's backward
+        buckets = GradBuckets([list(fine.parameters()), list(model.parameters())])
+        opt = FusedAdam(buckets.parameters(), lr=5e-4)   # torch.optim.Adam's update in one launch (tests/test_gpu_optim.py)
+        z_lin = torch.linspace(NEAR, FAR, N_COARSE).to(dev)
+        kw = dict(loss_fn=nerf_loss, white_bkgd=True, fine_model=fine, n_importance=N_FINE, u_fine=u_f)
+        near, far = NEAR, FAR
+
+    def step():
+        o, d, z, pts = ops.raygen_sample(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix, z_lin, u_c)
+        loss = train_step(model, o, d, gt, near, far, N_COARSE, chunk_rays=chunk_rays, buckets=buckets, samples=(z, pts), **kw)
+        opt.step()
+        return loss
+
+    return step, model
+
+
+def timed_steps(step, steps, warmup, world, dev):
+    import torch.distributed as dist
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return dt, float(loss.detach())
 
 
 def gpu_main(args):
     import torch.distributed as dist
-    from nerf_amd import ops
-    from nerf_amd.models.NeRF import NeRF
-    from nerf_amd.optim import FusedAdam
-    from nerf_amd.render import nerf_loss, render_rays
-    from nerf_amd.dist import GradAverager
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -77,87 +152,41 @@ def gpu_main(args):
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    c2w, pix, u_c, u_f, gt = make_batch(rank, args.rays, dev)
-    if args.model == "ngp":
-        # the hash-grid variant: 64 samples, one model, the weight regulariser of
-        # src/train_nerf_ngp.py:221-222 and its optimiser settings (:55); camera on the unit sphere
-        from nerf_amd.models.FastNGPNeRF import FastNGPNeRF
-        torch.manual_seed(0)
-        coarse = FastNGPNeRF().to(dev)
-        params = list(coarse.parameters())
-        opt = FusedAdam(params, lr=1e-2, eps=1e-15)
-        c2w = c2w.clone()
-        c2w[:, 3] = c2w[:, 3] / 4.03
-
-        def step():
-            o, d = ops.raygen(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix)
-            out = render_rays(coarse, o, d, NGP_NEAR, NGP_FAR, N_COARSE, perturb=True, t_rand=u_c, white_bkgd=False)
-            loss = torch.nn.functional.mse_loss(out["rgb"], gt) + 0.05 * (1.0 - out["weights"].sum(dim=-1)).abs().mean()
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            if averager is not None:
-                averager.average()
-            opt.step()
-            return loss
-    else:
-        torch.manual_seed(0)
-        coarse = NeRF().to(dev)
-        torch.manual_seed(1)
-        fine = NeRF().to(dev)
-        params = list(coarse.parameters()) + list(fine.parameters())
-        opt = FusedAdam(params, lr=5e-4)   # torch.optim.Adam's update in one launch (tests/test_gpu_optim.py)
-
-        def step():
-            o, d = ops.raygen(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix)
-            out = render_rays(coarse, o, d, NEAR, FAR, N_COARSE, perturb=True, t_rand=u_c, white_bkgd=True,
-                              fine_model=fine, n_importance=N_FINE, u_fine=u_f)
-            loss = nerf_loss(out, gt)
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            if averager is not None:
-                averager.average()
-            opt.step()
-            return loss
-    averager = GradAverager(params) if world > 1 else None
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    final_loss = float(loss.detach())
+    # one GPU: the 4096-ray batch the headline metric is quoted on; data parallel: 65,536 rays per GPU
+    rays = args.rays if args.rays else (RAYS_SINGLE if world == 1 else RAYS_DP)
+    chunk = args.chunk_rays
+    step, model = build_step(args.model, rank, rays, dev, chunk)
+    dt, final_loss = timed_steps(step, args.steps, args.warmup, world, dev)
+    secondary = None
+    if args.model == "vanilla" and not args.no_secondary:
+        # the hash-grid configuration, same camera and batch size, as a second result in the same line
+        del step
+        torch.cuda.empty_cache()
+        step2, ngp = build_step("ngp", rank, rays, dev, chunk)
+        n2 = max(5, args.steps)
+        dt2, loss2 = timed_steps(step2, n2, 3, world, dev)
+        if rank == 0:
+            secondary = {"metric": "rays/sec fwd+bwd (hash-grid model, 64 samples)", "value": world * rays * n2 / dt2,
+                         "unit": "rays/s", "n_gpus": world, "steps": n2, "ms_per_step": 1e3 * dt2 / n2, "dtype": "f32",
+                         "config": {"workload": NGP_WORKLOAD % rays, "rays_per_gpu": rays, "final_loss": loss2},
+                         "roofline": ngp_roofline(ngp, min(rays, 65536), dev)}
 
     result = None
     if rank == 0 and args.model == "ngp":
         result = {
-            "metric": "rays/sec fwd+bwd (hash-grid model, 64 samples)", "value": world * args.rays * args.steps / dt,
+            "metric": "rays/sec fwd+bwd (hash-grid model, 64 samples)", "value": world * rays * args.steps / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Instant-NGP variant (16 levels, 2^19 rows, 64-wide MLPs), 800x800 camera on the unit "
-                                   "sphere, 64 samples, %d-ray batch per GPU, one training step incl. Adam over the "
-                                   "tables" % args.rays,
-                       "rays_per_gpu": args.rays, "parallelism": "ray-sharded dp%d" % world, "final_loss": final_loss},
-            "roofline": ngp_roofline(coarse, args.rays, dev),
+            "config": {"workload": NGP_WORKLOAD % rays, "rays_per_gpu": rays, "parallelism": "ray-sharded dp%d" % world,
+                       "final_loss": final_loss},
+            "roofline": ngp_roofline(model, min(rays, 65536), dev),
         }
     elif rank == 0:
-        roof = kernel_roofline(coarse, args.rays, dev)
+        roof = kernel_roofline(model, min(rays, RAYS_SINGLE) if chunk is None else min(rays, chunk), dev)
         result = {
             "metric": "rays/sec fwd+bwd (lego 800x800, 64 coarse + 128 fine)",
-            "value": world * args.rays * args.steps / dt,
+            "value": world * rays * args.steps / dt,
             "unit": "rays/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -169,12 +198,16 @@ def gpu_main(args):
             "dtype": "f32 (operands split into 3 bf16 each, 6 bf16 MFMAs per product, fp32 accumulate: fp32-accurate)",
             "data": "synthetic",
             "config": {"workload": "vanilla NeRF 8x256 coarse+fine, Blender-lego-shaped 800x800 camera, "
-                                   "64 coarse + 128 fine samples, %d-ray batch per GPU, one training step "
-                                   "(ray-gen, sampling, MLPs, compositing, backward, Adam)" % args.rays,
-                       "rays_per_gpu": args.rays, "parallelism": "ray-sharded dp%d" % world,
+                                   "64 coarse + 128 fine samples, %d-ray batch per GPU%s, one training step "
+                                   "(fused ray-gen + sampling, MLPs, compositing, backward, %sAdam)"
+                                   % (rays, "" if rays <= RAYS_SINGLE else " in ray chunks with gradient accumulation",
+                                      "" if world == 1 else "bucketed RCCL all-reduce of the gradients, "),
+                       "rays_per_gpu": rays, "parallelism": "ray-sharded dp%d" % world,
                        "final_loss": final_loss},
             "roofline": roof,
         }
+        if secondary is not None:
+            result["secondary"] = secondary
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(args.cpu_rays)
     if world > 1:
@@ -269,45 +302,68 @@ def ngp_roofline(model, rays, dev):
             "frac": achieved / 8000.0, "traffic": None, "points_per_launch": P}
 
 
-def cpu_baseline(rays):
+def _cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(rays, rays_single=128):
     """The reference's op sequence (CPU PyTorch restatement in oracle/) on the host
     cores: same camera, same sampling, two 8x256 MLPs evaluated in 2048-point
-    chunks, compositing, loss, backward, Adam -- on a bounded ray sample."""
+    chunks, compositing, loss, backward, Adam -- on a bounded ray sample, with all
+    threads and with one."""
     from oracle import nerf_oracle as O
     threads = torch.get_num_threads()
-    torch.manual_seed(0)
-    coarse = O.NeRFOracle()
-    torch.manual_seed(1)
-    fine = O.NeRFOracle()
-    opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
-    g = torch.Generator().manual_seed(1)
-    pix = torch.randperm(H * W, generator=g)[:rays]
-    g2 = torch.Generator().manual_seed(2)
-    u_c = torch.rand(rays, N_COARSE, generator=g2)
-    u_f = torch.rand(rays, N_FINE, generator=g2)
-    gt = torch.rand(rays, 3, generator=torch.Generator().manual_seed(3))
-    c2w = lego_pose(0)
 
-    def step():
-        o, d = O.get_rays(c2w, (FOCAL, FOCAL), H, W)
-        o, d = o.reshape(-1, 3)[pix], d.reshape(-1, 3)[pix]
-        c_map, w, z, fine_out = O.render_rays(coarse, o, d, NEAR, FAR, N_COARSE, t_rand=u_c, chunk=2048,
-                                              white_bkgd=True, fine_model=fine, u_fine=u_f)
-        loss = torch.nn.functional.mse_loss(c_map, gt) + torch.nn.functional.mse_loss(fine_out[0], gt)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+    def run(n_rays):
+        torch.manual_seed(0)
+        coarse = O.NeRFOracle()
+        torch.manual_seed(1)
+        fine = O.NeRFOracle()
+        opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
+        g = torch.Generator().manual_seed(1)
+        pix = torch.randperm(H * W, generator=g)[:n_rays]
+        g2 = torch.Generator().manual_seed(2)
+        u_c = torch.rand(n_rays, N_COARSE, generator=g2)
+        u_f = torch.rand(n_rays, N_FINE, generator=g2)
+        gt = torch.rand(n_rays, 3, generator=torch.Generator().manual_seed(3))
+        c2w = lego_pose(0)
+        o_all, d_all = O.get_rays(c2w, (FOCAL, FOCAL), H, W)   # the reference generates the whole image's rays
 
-    step()
-    times = []
-    for _ in range(3):
-        t0 = time.perf_counter()
+        def step():
+            o, d = o_all.reshape(-1, 3)[pix], d_all.reshape(-1, 3)[pix]
+            c_map, w, z, fine_out = O.render_rays(coarse, o, d, NEAR, FAR, N_COARSE, t_rand=u_c, chunk=2048,
+                                                  white_bkgd=True, fine_model=fine, u_fine=u_f)
+            loss = torch.nn.functional.mse_loss(c_map, gt) + torch.nn.functional.mse_loss(fine_out[0], gt)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
         step()
-        times.append(time.perf_counter() - t0)
-    med = sorted(times)[1]
-    return {"value": rays / med, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": "%d-ray batch of the same workload (64c+128f, two 8x256 MLPs, fwd+bwd+Adam), "
-                      "median of 3 steps after 1 warm-up, torch %s CPU" % (rays, torch.__version__)}
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+        return n_rays / sorted(times)[1]
+
+    all_threads = run(rays)
+    torch.set_num_threads(1)
+    try:
+        one_thread = run(rays_single)
+    finally:
+        torch.set_num_threads(threads)
+    return {"value": all_threads, "unit": "rays/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": one_thread, "unit": "rays/s", "cores": 1, "sample": "%d-ray batch" % rays_single},
+            "cpu": _cpu_model_name(), "host_cpus": os.cpu_count(), "torch": torch.__version__,
+            "sample": "%d-ray batch of the same workload (64c+128f, two 8x256 MLPs in 2048-point chunks, fwd+bwd+Adam), "
+                      "median of 3 steps after 1 warm-up" % rays}
 
 
 def main():
@@ -315,10 +371,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--rays", type=int, default=0, help="rays per GPU per step (default: 4096 on one GPU, 65536 per GPU on several)")
+    ap.add_argument("--chunk-rays", type=int, default=None, help="rays per forward/backward chunk (default: what fits 32 GiB of workspace)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the hash-grid result that rides along as 'secondary'")
     ap.add_argument("--model", choices=["vanilla", "ngp"], default="vanilla",
                     help="vanilla = the headline workload; ngp = the hash-grid variant (secondary line)")
-    ap.add_argument("--cpu-rays", type=int, default=512, help="ray sample of the CPU baseline")
+    ap.add_argument("--cpu-rays", type=int, default=1024, help="ray sample of the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))

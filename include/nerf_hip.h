@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 1
+#define NERF_ABI_VERSION 2
 #define NERF_OK 0
 #define NERF_EINVAL (-22) /* bad argument (shape, null pointer, unsupported size) */
 #define NERF_ELAUNCH (-5) /* the HIP runtime rejected a launch                    */
@@ -38,7 +38,11 @@ const char* nerf_last_error(void);
 
 /* Camera.get_rays, src/Camera.py:49-72.  c2w: 12 floats, rows of the 3x4 pose.
  * Pixel id p = row*W + col.  pix == NULL renders all H*W pixels in order (R must
- * be H*W); otherwise pix holds R int32 pixel ids.  rays_o, rays_d: [R,3]. */
+ * be H*W); otherwise pix holds R int32 pixel ids.  rays_o, rays_d: [R,3].  A pixel
+ * id outside [0, H*W) yields a NaN ray.
+ * The older free function get_rays(H, W, focal, c2w) of src/utils/get_rays.py:115-147
+ * (+z forward, [W,H,3] output) is this call with the third pose column negated,
+ * fx = fy = focal, cx = W/2, cy = H/2 and pix = the transposed pixel order. */
 int nerf_raygen(const float* c2w, float fx, float fy, float cx, float cy, int H, int W,
                 const int32_t* pix, int64_t R, float* rays_o, float* rays_d, void* stream);
 
@@ -46,7 +50,8 @@ int nerf_raygen(const float* c2w, float fx, float fy, float cx, float cy, int H,
  * time (Camera.get_rays per DataLoader item, src/train_nerf_skow.py:132-146, src/train_nerf_llff.py:106-111).
  * cams: [n_cams][16] = 12 floats of the 3x4 pose, fx, fy, cx, cy; ray r looks through pixel pix[r]
  * (row*W + col, all images H x W) of camera cam_id[r].  images: [n_cams][H*W][3] or NULL; when given,
- * rgb [R,3] receives the pixels' colours.  Ids are the caller's to keep in range. */
+ * rgb [R,3] receives the pixels' colours.  A camera id outside [0, n_cams) or a pixel id
+ * outside [0, H*W) reads nothing and yields NaN rays (and colours). */
 int nerf_raygen_multi(const float* cams, int n_cams, int H, int W, const int32_t* cam_id,
                       const int32_t* pix, int64_t R, const float* images, float* rays_o,
                       float* rays_d, float* rgb, void* stream);
@@ -108,9 +113,14 @@ int nerf_hashgrid_bwd(const float* x, int64_t P, const float* d_out, const int* 
 /* Camera.volume_render, src/Camera.py:143-183.  rgb [R,N,3], sigma [R,N],
  * z [R,N] -> out_rgb [R,3], weights [R,N]; depth [R] = sum w*z (may be NULL; the
  * reference has no depth output).  2 <= N <= 1024 (for N = 1 the reference's
- * tail-distance concat yields empty tensors; that case is rejected here). */
+ * tail-distance concat yields empty tensors; that case is rejected here).
+ * tail_dist: the distance appended after the last sample, 1e5 for Camera.volume_render
+ * (src/Camera.py:154) and 1e10 for the older volume_render of src/utils/get_rays.py:198-236. */
+#define NERF_TAIL_CAMERA 1e5f
+#define NERF_TAIL_LEGACY 1e10f
 int nerf_composite_fwd(const float* rgb, const float* sigma, const float* z, int64_t R, int N,
-                       int white_bkgd, float* out_rgb, float* weights, float* depth, void* stream);
+                       int white_bkgd, float tail_dist, float* out_rgb, float* weights, float* depth,
+                       void* stream);
 
 /* Backward of volume_render for a loss that reads out_rgb, weights and depth
  * (the reference's NGP loss uses both outputs, src/train_nerf_ngp.py:221-222).
@@ -118,7 +128,17 @@ int nerf_composite_fwd(const float* rgb, const float* sigma, const float* z, int
  * Outputs d_rgb [R,N,3], d_sigma [R,N]. */
 int nerf_composite_bwd(const float* rgb, const float* sigma, const float* z, const float* d_out,
                        const float* d_weights, const float* d_depth, int64_t R, int N,
-                       int white_bkgd, float* d_rgb, float* d_sigma, void* stream);
+                       int white_bkgd, float tail_dist, float* d_rgb, float* d_sigma, void* stream);
+
+/* Occupancy-grid masking of per-sample densities, the step between the model and the compositor in
+ * render_image (src/train_nerf_ngp.py:113-117) and render_from_model
+ * (src/utils/analyze_capture_results.py:283-287): out[p] = values[p] where grid[cell(p)] == 1, else 0, with
+ * cell(p) = x + 32 y + 1024 z of the truncated ((pts + 1) / 2) / (1 / grid_res) (xyz_to_idx keeps its default
+ * res = 32, :230-231).  pts [P,3], values/out [P] (in place allowed), grid: grid_cells bytes.  A cell index
+ * outside the grid (an IndexError in the reference) is clamped into it.  The same call applied to d_sigma
+ * is the backward: masked samples receive no gradient. */
+int nerf_occupancy_mask(const float* pts, const float* values, int64_t P, const uint8_t* grid,
+                        int64_t grid_cells, int grid_res, float* out, void* stream);
 
 /* ---------------------------------------------------------- fused MLPs ---- */
 
@@ -158,6 +178,12 @@ int nerf_mlp_vanilla_fwd(const float* x, const float* dirs, int dirs_div, int64_
 int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, int64_t P, const float* packed,
                          const float* rgb, const float* sigma, float* ws, float* ws2,
                          int skip_h_first, float* const* grads, int phases, void* stream);
+/* Which ReLUs the forward pass found open (F.relu at src/models/NeRF.py:87 and inside rgb_layers, :58-63),
+ * read back from its workspace for parity checks: out [P][NERF_VANILLA_MASK_ROW] bytes, 0 or 1;
+ * out[p][256 l + n] = neuron n of trunk layer l (0..7), out[p][2048 + n] = neuron n of the colour hidden
+ * layer (0..127). */
+#define NERF_VANILLA_MASK_ROW 2176
+int nerf_mlp_vanilla_relu_masks(const float* ws, int64_t P, uint8_t* out, void* stream);
 
 /* Hash-grid NeRF, FastNGPNeRF.forward (src/models/FastNGPNeRF.py:79-110), fused:
  * 16-level hash encoding (src/utils/hash_grid_encoder.py:42-107) + density MLP +
@@ -190,15 +216,25 @@ int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, i
                      const float* sigma, float* ws, float* ws2, float* const* d_tables,
                      float* const* grads, void* stream);
 
-/* One Adam step over `count` tensors in one launch: torch.optim.Adam with its default
- * options (no weight decay, no amsgrad), the optimiser of the reference's training loops
- * (src/train_nerf_llff.py:82 lr 5e-4; src/train_nerf_ngp.py:55 lr 1e-2, eps 1e-15).
+/* One Adam step over `count` tensors in one launch: torch.optim.Adam (no amsgrad), the optimiser
+ * of the reference's training loops (src/train_nerf_llff.py:82 and src/train_nerf_skow.py:47: lr 5e-4,
+ * weight_decay 1e-6; src/train_nerf_ngp.py:55: lr 1e-2, eps 1e-15).  weight_decay is torch's L2 form
+ * (grad + weight_decay * param enters the moments).
  * Host arrays of device pointers params/grads/exp_avg/exp_avg_sq [count] and element
  * counts numel [count]; step = 1 for the first step.  Updates params, exp_avg and
  * exp_avg_sq in place. */
 int nerf_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, int64_t step, float lr, float beta1,
-                   float beta2, float eps, void* stream);
+                   float beta2, float eps, float weight_decay, void* stream);
+
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) with the 2-norm (src/train_nerf.py:165):
+ * total = the norm of all gradients together, every gradient is multiplied by
+ * min(1, max_norm / (total + 1e-6)) in place.  grads/numel: host arrays [count]; total_norm: one
+ * device float that receives total (may be NULL).  workspace: device scratch of
+ * nerf_clip_grad_norm_workspace_floats(count, numel) floats; nothing is read back to the host. */
+size_t nerf_clip_grad_norm_workspace_floats(int count, const int64_t* numel);
+int nerf_clip_grad_norm(int count, float* const* grads, const int64_t* numel, float max_norm,
+                        float* workspace, float* total_norm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -94,7 +94,7 @@ class Camera:
         reference, exactly two leading dimensions are expected."""
         H, W = rays_o.shape[:2]
         dev = rays_o.device
-        z_lin = torch.linspace(near, far, N_samples, device=dev)
+        z_lin = torch.linspace(near, far, N_samples).to(dev)   # the reference's CPU linspace values, bit for bit
         if perturb and t_rand is None:
             t_rand = torch.rand(H, W, N_samples, device=dev)
         u = t_rand.reshape(H * W, N_samples) if perturb else None

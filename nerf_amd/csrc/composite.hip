@@ -1,7 +1,9 @@
-// Alpha compositing (Camera.volume_render, src/Camera.py:143-183) and its
-// backward for gfx950.  One wavefront owns a ray at a time; lane l holds IPL consecutive
-// samples, the exclusive transmittance product is a lane-local prefix followed
-// by a 64-lane shuffle scan, and the backward uses the mirrored suffix scan.
+// Alpha compositing (Camera.volume_render, src/Camera.py:143-183; the older free function
+// volume_render of src/utils/get_rays.py:198-236 differs only in the distance appended after the
+// last sample, 1e10 instead of 1e5, which is the `tail` argument) and its backward for gfx950.
+// One wavefront owns a ray at a time; lane l holds IPL consecutive samples, the exclusive
+// transmittance product is a lane-local prefix followed by a 64-lane shuffle scan, and the
+// backward uses the mirrored suffix scan.
 // Bandwidth-bound: 20 B/sample in, 4 B/sample out (forward).
 // Compiled with -ffp-contract=off: alpha, 1-alpha+1e-10 and w round like the
 // reference's separate ops.
@@ -73,7 +75,7 @@ struct RaySlice {
         }
     }
 
-    __device__ __forceinline__ void compute(int N, int lane) {
+    __device__ __forceinline__ void compute(int N, int lane, float tail) {
         const int base = lane * IPL;
         float lane_prod = 1.0f;
         // z of the next sample: the next register, or the next lane's first one
@@ -82,7 +84,7 @@ struct RaySlice {
         for (int k = 0; k < IPL; ++k) {
             const int i = base + k;
             const float zn = (k + 1 < IPL) ? zz[(k + 1) % IPL] : z_next_lane;
-            dist[k] = (i == N - 1) ? 1e5f : zn - zz[k];         // src/Camera.py:153-154
+            dist[k] = (i == N - 1) ? tail : zn - zz[k];         // src/Camera.py:153-154
             alpha[k] = ok[k] ? 1.0f - expf(-sig[k] * dist[k]) : 0.0f;  // :156
             tr[k] = ok[k] ? (1.0f - alpha[k]) + 1e-10f : 1.0f;   // :163
             T[k] = lane_prod;                                     // lane-local exclusive product
@@ -107,7 +109,7 @@ struct RaysPerWave {
 template <int IPL, bool FULL>
 __global__ __launch_bounds__(CMP_WAVES * 64) void composite_fwd_kernel(
     const float* __restrict__ rgb, const float* __restrict__ sigma, const float* __restrict__ z, int64_t R, int N,
-    int white, float* __restrict__ out_rgb, float* __restrict__ weights, float* __restrict__ depth) {
+    int white, float tail, float* __restrict__ out_rgb, float* __restrict__ weights, float* __restrict__ depth) {
     constexpr int RPW = RaysPerWave<IPL>::value;
     const int lane = threadIdx.x & 63;
     const int64_t ray0 = ((int64_t)blockIdx.x * CMP_WAVES + (threadIdx.x >> 6)) * RPW;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(CMP_WAVES * 64) void composite_fwd_kernel(
     for (int q = 0; q < RPW; ++q) {
         const int64_t ray = ray0 + q;
         if (ray >= R) break;  // uniform over the wave
-        s[q].compute(N, lane);
+        s[q].compute(N, lane, tail);
         float c0 = 0.f, c1 = 0.f, c2 = 0.f, ws = 0.f, dz = 0.f;
         float wout[IPL];
 #pragma unroll
@@ -165,7 +167,7 @@ template <int IPL, bool FULL>
 __global__ __launch_bounds__(CMP_WAVES * 64) void composite_bwd_kernel(
     const float* __restrict__ rgb, const float* __restrict__ sigma, const float* __restrict__ z,
     const float* __restrict__ d_out, const float* __restrict__ d_weights, const float* __restrict__ d_depth, int64_t R,
-    int N, int white, float* __restrict__ d_rgb, float* __restrict__ d_sigma) {
+    int N, int white, float tail, float* __restrict__ d_rgb, float* __restrict__ d_sigma) {
     constexpr int RPW = RaysPerWave<IPL>::value;
     const int lane = threadIdx.x & 63;
     const int64_t ray0 = ((int64_t)blockIdx.x * CMP_WAVES + (threadIdx.x >> 6)) * RPW;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(CMP_WAVES * 64) void composite_bwd_kernel(
     for (int q = 0; q < RPW; ++q) {
         const int64_t ray = ray0 + q;
         if (ray >= R) break;
-        s[q].compute(N, lane);
+        s[q].compute(N, lane, tail);
         const float g0 = d_out[ray * 3 + 0], g1 = d_out[ray * 3 + 1], g2 = d_out[ray * 3 + 2];
         const float gbg = white ? -((g0 + g1) + g2) : 0.0f;
         const float gdz = d_depth ? d_depth[ray] : 0.0f;
@@ -233,6 +235,27 @@ __global__ __launch_bounds__(CMP_WAVES * 64) void composite_bwd_kernel(
     }
 }
 
+// Occupancy-grid masking of per-sample values (src/train_nerf_ngp.py:113-117,
+// src/utils/analyze_capture_results.py:283-287): cell = trunc(((p + 1) / 2) / cell_size) per axis,
+// flat index x + 32 y + 1024 z (the reference's xyz_to_idx keeps its default res = 32 whatever the
+// grid resolution is), value kept where grid[index] == 1 and zeroed elsewhere.  An index outside
+// the grid, an IndexError in the reference, is clamped to the nearest stored cell.
+__global__ __launch_bounds__(256) void occupancy_mask_kernel(const float* __restrict__ pts, const float* __restrict__ in,
+                                                             int64_t P, const uint8_t* __restrict__ grid, int64_t cells,
+                                                             float cell, float* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    long long c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = ((pts[3 * p + k] + 1.0f) / 2.0f) / cell;
+        c[k] = v >= 9.0e18f ? (long long)9.0e18f : v <= -9.0e18f ? -(long long)9.0e18f : v != v ? 0 : (long long)v;   // .long() truncates
+    }
+    long long idx = c[0] + c[1] * 32 + c[2] * 1024;
+    idx = idx < 0 ? 0 : idx >= cells ? cells - 1 : idx;
+    out[p] = grid[idx] == 1 ? in[p] : 0.0f;
+}
+
 }  // namespace nerf
 
 using namespace nerf;
@@ -255,20 +278,33 @@ using namespace nerf;
     } while (0)
 
 extern "C" int nerf_composite_fwd(const float* rgb, const float* sigma, const float* z, int64_t R, int N,
-                                  int white_bkgd, float* out_rgb, float* weights, float* depth, void* stream) {
+                                  int white_bkgd, float tail_dist, float* out_rgb, float* weights, float* depth,
+                                  void* stream) {
     if (R == 0) return NERF_OK;
     NERF_REQUIRE(rgb && sigma && z && out_rgb && weights, "nerf_composite_fwd: null pointer");
     NERF_REQUIRE(R >= 0 && N >= 2 && N <= 1024, "nerf_composite_fwd: R=%lld N=%d (N must be 2..1024)", (long long)R, N);
-    CMP_DISPATCH(composite_fwd_kernel, rgb, sigma, z, R, N, white_bkgd, out_rgb, weights, depth);
+    CMP_DISPATCH(composite_fwd_kernel, rgb, sigma, z, R, N, white_bkgd, tail_dist, out_rgb, weights, depth);
     return check_launch("nerf_composite_fwd");
 }
 
 extern "C" int nerf_composite_bwd(const float* rgb, const float* sigma, const float* z, const float* d_out,
                                   const float* d_weights, const float* d_depth, int64_t R, int N, int white_bkgd,
-                                  float* d_rgb, float* d_sigma, void* stream) {
+                                  float tail_dist, float* d_rgb, float* d_sigma, void* stream) {
     if (R == 0) return NERF_OK;
     NERF_REQUIRE(rgb && sigma && z && d_out && d_rgb && d_sigma, "nerf_composite_bwd: null pointer");
     NERF_REQUIRE(R >= 0 && N >= 2 && N <= 1024, "nerf_composite_bwd: R=%lld N=%d (N must be 2..1024)", (long long)R, N);
-    CMP_DISPATCH(composite_bwd_kernel, rgb, sigma, z, d_out, d_weights, d_depth, R, N, white_bkgd, d_rgb, d_sigma);
+    CMP_DISPATCH(composite_bwd_kernel, rgb, sigma, z, d_out, d_weights, d_depth, R, N, white_bkgd, tail_dist, d_rgb, d_sigma);
     return check_launch("nerf_composite_bwd");
+}
+
+extern "C" int nerf_occupancy_mask(const float* pts, const float* values, int64_t P, const uint8_t* grid,
+                                   int64_t grid_cells, int grid_res, float* out, void* stream) {
+    if (P == 0) return NERF_OK;
+    NERF_REQUIRE(pts && values && grid && out, "nerf_occupancy_mask: null pointer");
+    NERF_REQUIRE(P >= 0 && grid_cells >= 1 && grid_res >= 1, "nerf_occupancy_mask: P=%lld cells=%lld res=%d", (long long)P,
+                 (long long)grid_cells, grid_res);
+    const float cell = (float)(1.0 / (double)grid_res);   // the Python float 1.0/grid_res, rounded where the tensor op consumes it
+    hipLaunchKernelGGL(occupancy_mask_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, pts,
+                       values, P, grid, grid_cells, cell, out);
+    return check_launch("nerf_occupancy_mask");
 }

@@ -2,6 +2,8 @@
 // multiresolution hash grid (forward gather + trilinear interpolation, backward
 // scatter with float atomics).  Compiled with -ffp-contract=off so the
 // interpolation rounds like the reference's separate PyTorch ops.
+#include <atomic>
+
 #include "common.h"
 #include "hashgrid.h"
 
@@ -200,12 +202,16 @@ extern "C" int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* 
 
 int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, const int* res, const int* sizes,
                                   int levels, float* const* d_tables, hipStream_t stream) {
-    static bool lds_enabled = false;   // idempotent: the attribute belongs to the kernel, not to a call
-    if (!lds_enabled) {
+    // The raised dynamic-LDS limit belongs to (kernel, device): remembered per device.  Setting it twice is
+    // harmless, so two threads racing on a flag only repeat the call.
+    static std::atomic<bool> lds_enabled[64];
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return fail(NERF_ELAUNCH, "hashgrid_scatter: no current device");
+    if (device < 0 || device >= 64 || !lds_enabled[device].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(hashgrid_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(HG_LDS_MAX_ROWS * 2 * sizeof(float))) != hipSuccess)
             return fail(NERF_ELAUNCH, "hashgrid_scatter: cannot raise the LDS limit");
-        lds_enabled = true;
+        if (device >= 0 && device < 64) lds_enabled[device].store(true, std::memory_order_release);
     }
     HashGradLevels lv;
     int big = 0;

@@ -276,9 +276,32 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
     save_tiles<8>(tb, ws2 + ix.P32 * vw::DY + ix.tile * 32 * 256, 256, b);
 }
 
+// The ReLU bits the forward pass saved, one byte per neuron: out[p][256 l + n] for the trunk layers l = 0..7,
+// out[p][2048 + n] for the 128 neurons of the colour hidden layer.
+constexpr int MASK_ROW = 8 * 256 + 128;
+__global__ __launch_bounds__(256) void relu_mask_dump_kernel(const float* __restrict__ ws, long long P, long long P32,
+                                                             uint8_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * MASK_ROW) return;
+    const long long gp = i / MASK_ROW;
+    const int c = (int)(i - gp * MASK_ROW), l = c >> 8, n = c & 255;
+    const int t = n >> 5, e = n & 31, h = (e >> 2) & 1, r = (e & 3) + 4 * (e >> 3);   // rowmap(r, h) == e
+    const unsigned* words = reinterpret_cast<const unsigned*>(ws + P32 * vw::MASK) + (((gp >> 5) * 9 + l) * 64 + (gp & 31) + 32 * h) * 4;
+    out[i] = (uint8_t)((words[t >> 1] >> ((t & 1) * 16 + r)) & 1u);
+}
+
 }  // namespace nerf
 
 using namespace nerf;
+
+extern "C" int nerf_mlp_vanilla_relu_masks(const float* ws, int64_t P, uint8_t* out, void* stream) {
+    if (P == 0) return NERF_OK;
+    NERF_REQUIRE(ws && out && P > 0, "nerf_mlp_vanilla_relu_masks: null pointer or P=%lld", (long long)P);
+    const long long total = (long long)P * MASK_ROW;
+    hipLaunchKernelGGL(relu_mask_dump_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, ws,
+                       (long long)P, (long long)((P + 31) / 32 * 32), out);
+    return check_launch("nerf_mlp_vanilla_relu_masks");
+}
 
 extern "C" size_t nerf_mlp_vanilla_pack_floats(void) { return vp::TOTAL; }
 extern "C" size_t nerf_mlp_vanilla_ws_floats_per_point(void) { return vw::PER_POINT; }

@@ -28,29 +28,41 @@ __device__ __forceinline__ void pixel_ray(const float* __restrict__ c2w, float f
     }
 }
 
-__global__ void raygen_kernel(const float* __restrict__ c2w, float fx, float fy, float cx, float cy, int W,
+__global__ void raygen_kernel(const float* __restrict__ c2w, float fx, float fy, float cx, float cy, int W, int HW,
                               const int32_t* __restrict__ pix, int64_t R, float* __restrict__ rays_o,
                               float* __restrict__ rays_d) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     float o[3], d[3];
-    pixel_ray(c2w, fx, fy, cx, cy, W, pix ? pix[r] : (int)r, o, d);
+    const int px = pix ? pix[r] : (int)r;
+    pixel_ray(c2w, fx, fy, cx, cy, W, px, o, d);
+    const bool ok = (unsigned)px < (unsigned)HW;   // a pixel id outside the image yields a NaN ray
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        rays_o[3 * r + k] = o[k];
-        rays_d[3 * r + k] = d[k];
+        rays_o[3 * r + k] = ok ? o[k] : __builtin_nanf("");
+        rays_d[3 * r + k] = ok ? d[k] : __builtin_nanf("");
     }
 }
 
 // Rays of a batch drawn across many cameras: ray r looks through pixel pix[r] of camera cam_id[r].
 // cams: [n][16] = the 12 floats of the 3x4 pose, then fx, fy, cx, cy.  With images ([n][H*W][3]) the
 // pixel's colour is gathered alongside (the training target), so a batch costs one pass.
-__global__ void raygen_multi_kernel(const float* __restrict__ cams, int W, int64_t HW, const int32_t* __restrict__ cam_id,
+// A camera or pixel id out of range reads nothing and yields NaN rays and colours.
+__global__ void raygen_multi_kernel(const float* __restrict__ cams, int n_cams, int W, int64_t HW, const int32_t* __restrict__ cam_id,
                                     const int32_t* __restrict__ pix, int64_t R, const float* __restrict__ images,
                                     float* __restrict__ rays_o, float* __restrict__ rays_d, float* __restrict__ rgb) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const int c = cam_id[r], px = pix[r];
+    if ((unsigned)c >= (unsigned)n_cams || (unsigned)px >= (unsigned)HW) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rays_o[3 * r + k] = __builtin_nanf("");
+            rays_d[3 * r + k] = __builtin_nanf("");
+            if (images) rgb[3 * r + k] = __builtin_nanf("");
+        }
+        return;
+    }
     const float* cam = cams + 16 * (int64_t)c;
     float pose[12];
 #pragma unroll
@@ -363,7 +375,7 @@ extern "C" int nerf_raygen(const float* c2w, float fx, float fy, float cx, float
     NERF_REQUIRE(pix || R == (int64_t)H * W, "nerf_raygen: R=%lld must equal H*W when pix is NULL", (long long)R);
     NERF_REQUIRE((int64_t)H * W < (1ll << 31), "nerf_raygen: image too large");
     hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, c2w, fx, fy,
-                       cx, cy, W, pix, R, rays_o, rays_d);
+                       cx, cy, W, H * W, pix, R, rays_o, rays_d);
     return check_launch("nerf_raygen");
 }
 
@@ -375,7 +387,7 @@ extern "C" int nerf_raygen_multi(const float* cams, int n_cams, int H, int W, co
                  (long long)R);
     NERF_REQUIRE((int64_t)H * W < (1ll << 31), "nerf_raygen_multi: image too large");
     NERF_REQUIRE(!images || rgb, "nerf_raygen_multi: images given without an rgb output");
-    hipLaunchKernelGGL(raygen_multi_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, cams, W,
+    hipLaunchKernelGGL(raygen_multi_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, cams, n_cams, W,
                        (int64_t)H * W, cam_id, pix, R, images, rays_o, rays_d, rgb);
     return check_launch("nerf_raygen_multi");
 }

@@ -3,14 +3,23 @@ the ``nccl`` backend (RCCL over xGMI on ROCm); ``gloo`` works for CPU rehearsal.
 
 The reference is single-process.  Rays are independent, so the only exchange of
 a training step is the parameter-gradient average: every rank renders its own
-ray batch with replicated parameters, the gradients are summed in ONE flat
-all-reduce per step (2.4 MB per vanilla MLP, 41.8 MB for the hash-grid model)
-and every rank applies the same optimiser update.  Inference needs only a final
+ray batch with replicated parameters, the gradients are summed across ranks and
+every rank applies the same optimiser update.  Inference needs only a final
 gather of the rendered rows.
+
+Gradient layout: the parameters are grouped into buckets (one per model: 2.4 MB
+for a vanilla MLP; hash tables 41.7 MB and the small matrices of the hash-grid
+model) and each bucket's gradients live in ONE flat buffer, ``p.grad`` being
+views into it.  A step is then: one memset per bucket, backward passes that
+accumulate in place (any number of ray chunks), and one all-reduce per bucket
+on the buffer itself -- no copy-in, no divide pass, no copy-out.  The all-reduce
+of a bucket is issued from a gradient hook the moment the last chunk's backward
+has delivered that bucket, so with a coarse and a fine model the fine model's
+exchange runs under the coarse model's backward.
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Tuple
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -23,9 +32,129 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+class GradBuckets:
+    """Flat gradient storage for groups of parameters, with the cross-rank sum.
+
+    ``buckets``: a list of parameter lists (or one flat list = one bucket).  Works without
+    ``torch.distributed`` too (world size 1: the flat storage and single memset remain).
+
+        gb = GradBuckets([list(fine.parameters()), list(coarse.parameters())])
+        gb.zero_grad()                # instead of optimizer.zero_grad()
+        ... backward passes of all but the last ray chunk ...
+        gb.arm()                      # the next backward completes the gradients
+        last_loss.backward()          # hooks launch each bucket's all-reduce as it completes
+        gb.finish()                   # wait; p.grad now holds the sum over ranks
+    Scale the loss by ``1 / world`` (``grad_scale``) to get the average.
+    """
+
+    def __init__(self, buckets: Sequence, group=None):
+        if buckets and isinstance(buckets[0], torch.nn.Parameter):
+            buckets = [list(buckets)]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.buckets: List[List[torch.nn.Parameter]] = [[p for p in b if p.requires_grad] for b in buckets]
+        self.buckets = [b for b in self.buckets if b]
+        self.flats: List[torch.Tensor] = []
+        self.views: List[List[torch.Tensor]] = []
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in b), device=b[0].device, dtype=torch.float32)
+            views, off = [], 0
+            for p in b:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._delivered(bi)))
+            self.flats.append(flat)
+            self.views.append(views)
+        self._armed = False
+        self._missing = [0] * len(self.buckets)
+        self._work: List[Optional[object]] = [None] * len(self.buckets)
+        self._sent = [False] * len(self.buckets)
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def zero_grad(self) -> None:
+        """One memset per bucket; (re)installs ``p.grad`` as views of the flat buffers."""
+        for flat, b, views in zip(self.flats, self.buckets, self.views):
+            flat.zero_()
+            for p, v in zip(b, views):
+                if p.grad is not v:
+                    p.grad = v
+        self._armed = False
+        self._work = [None] * len(self.buckets)
+        self._sent = [False] * len(self.buckets)
+
+    def arm(self) -> None:
+        """Announce that the next backward pass completes the gradients of this step."""
+        self._armed = True
+        self._missing = [len(b) for b in self.buckets]
+
+    def _send(self, bi: int) -> None:
+        self._sent[bi] = True
+        if self.world > 1:
+            self._work[bi] = dist.all_reduce(self.flats[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _delivered(self, bi: int) -> None:
+        if not self._armed:
+            return
+        self._missing[bi] -= 1
+        if self._missing[bi] == 0 and not self._sent[bi]:
+            self._send(bi)
+
+    def finish(self) -> None:
+        """Send what no hook has sent (parameters the last backward did not reach), wait for all."""
+        for bi in range(len(self.buckets)):
+            if not self._sent[bi]:
+                self._send(bi)
+        for w in self._work:
+            if w is not None:
+                w.wait()
+        self._armed = False
+
+    def parameters(self) -> List[torch.nn.Parameter]:
+        return [p for b in self.buckets for p in b]
+
+    def remove_hooks(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def accumulate_step(n_items: int, chunk: int, loss_of_chunk: Callable[[int, int], torch.Tensor],
+                    buckets: Optional[GradBuckets] = None, grad_scale: Optional[float] = None) -> torch.Tensor:
+    """Forward + backward over ``n_items`` rays in chunks of at most ``chunk``, accumulating the parameter
+    gradients, so that activation memory is bounded by one chunk -- the counterpart of the reference's chunk
+    loop (src/train_nerf_llff.py:50-56) and of its halve-on-OOM retry (src/train_nerf.py:34-44), moved from
+    the model call to the whole step.
+
+    ``loss_of_chunk(lo, hi)`` returns a loss that is a MEAN over rays lo..hi; it is weighted by
+    (hi - lo) / n_items, so the accumulated gradient is that of the mean over all rays.  With ``buckets`` the
+    gradients land in its flat buffers and the cross-rank sum starts under the last chunk's backward;
+    ``grad_scale`` defaults to 1 / world size.  Returns the detached total loss (a 0-d tensor, no host sync).
+    """
+    if grad_scale is None:
+        grad_scale = buckets.grad_scale if buckets is not None else 1.0
+    if buckets is not None:
+        buckets.zero_grad()
+    total = None
+    spans = [(lo, min(lo + chunk, n_items)) for lo in range(0, n_items, chunk)]
+    for k, (lo, hi) in enumerate(spans):
+        loss = loss_of_chunk(lo, hi) * ((hi - lo) / n_items)
+        if buckets is not None and k == len(spans) - 1:
+            buckets.arm()
+        (loss * grad_scale if grad_scale != 1.0 else loss).backward()
+        total = loss.detach() if total is None else total + loss.detach()
+    if buckets is not None:
+        buckets.finish()
+    return total
+
+
 class GradAverager:
-    """Averages ``p.grad`` of the given parameters over all ranks with a single
-    flat all-reduce.  Parameters whose grad is None on this rank contribute zeros."""
+    """Averages ``p.grad`` of the given parameters over all ranks with a single flat all-reduce, for
+    gradients that already exist as ordinary tensors (``GradBuckets`` avoids the copies).  Parameters
+    whose grad is None on this rank contribute zeros."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]

@@ -177,7 +177,7 @@ class _Composite(torch.autograd.Function):
     """(rgb [R,N,3], sigma [R,N], z [R,N]) -> (colour [R,3], weights [R,N], depth [R])."""
 
     @staticmethod
-    def forward(ctx, rgb, sigma, z, white_bkgd):
+    def forward(ctx, rgb, sigma, z, white_bkgd, tail):
         L.need_gpu(rgb, sigma, z)
         rgb_c, sig_c, z_c = L.f32c(rgb.detach()), L.f32c(sigma.detach()), L.f32c(z.detach())
         R, N = sig_c.shape
@@ -185,10 +185,11 @@ class _Composite(torch.autograd.Function):
         w = torch.empty(R, N, device=rgb_c.device)
         depth = torch.empty(R, device=rgb_c.device)
         L.check(L.lib().nerf_composite_fwd(L.ptr(rgb_c), L.ptr(sig_c), L.ptr(z_c), R, N, int(bool(white_bkgd)),
-                                           L.ptr(out), L.ptr(w), L.ptr(depth), L.stream_of(rgb_c)),
+                                           float(tail), L.ptr(out), L.ptr(w), L.ptr(depth), L.stream_of(rgb_c)),
                 "nerf_composite_fwd")
         ctx.save_for_backward(rgb_c, sig_c, z_c)
         ctx.white = int(bool(white_bkgd))
+        ctx.tail = float(tail)
         ctx.set_materialize_grads(False)
         return out, w, depth
 
@@ -202,17 +203,56 @@ class _Composite(torch.autograd.Function):
         d_rgb = torch.empty_like(rgb_c)
         d_sigma = torch.empty_like(sig_c)
         L.check(L.lib().nerf_composite_bwd(L.ptr(rgb_c), L.ptr(sig_c), L.ptr(z_c), L.ptr(d_out), L.ptr(d_w),
-                                           L.ptr(d_depth), R, N, ctx.white, L.ptr(d_rgb), L.ptr(d_sigma),
+                                           L.ptr(d_depth), R, N, ctx.white, ctx.tail, L.ptr(d_rgb), L.ptr(d_sigma),
                                            L.stream_of(rgb_c)), "nerf_composite_bwd")
-        return d_rgb, d_sigma, None, None
+        return d_rgb, d_sigma, None, None, None
 
 
-def composite(rgb, sigma, z, white_bkgd: bool = False):
-    """Alpha compositing over the last sample axis; leading axes are flattened to rays."""
+TAIL_CAMERA = 1e5    # Camera.volume_render, src/Camera.py:154
+TAIL_LEGACY = 1e10   # volume_render of src/utils/get_rays.py:214
+
+
+def composite(rgb, sigma, z, white_bkgd: bool = False, tail: float = TAIL_CAMERA):
+    """Alpha compositing over the last sample axis; leading axes are flattened to rays.
+    ``tail`` is the distance appended after the last sample."""
     lead = sigma.shape[:-1]
     N = sigma.shape[-1]
-    out, w, depth = _Composite.apply(rgb.reshape(-1, N, 3), sigma.reshape(-1, N), z.reshape(-1, N), white_bkgd)
+    out, w, depth = _Composite.apply(rgb.reshape(-1, N, 3), sigma.reshape(-1, N), z.reshape(-1, N), white_bkgd, tail)
     return out.view(*lead, 3), w.view(*lead, N), depth.view(*lead)
+
+
+class _OccupancyMask(torch.autograd.Function):
+    """sigma [P] -> sigma with the samples in empty occupancy cells zeroed; they get no gradient."""
+
+    @staticmethod
+    def forward(ctx, sigma, pts, grid, grid_res):
+        L.need_gpu(sigma, pts, grid)
+        sc, pc = L.f32c(sigma.detach()).reshape(-1), L.f32c(pts.detach()).reshape(-1, 3)
+        assert pc.shape[0] == sc.shape[0], "one point per density"
+        if grid.dtype != torch.uint8:
+            raise L.NerfHipError("the occupancy grid must be uint8")
+        gc = grid.contiguous()
+        out = torch.empty_like(sc)
+        L.check(L.lib().nerf_occupancy_mask(L.ptr(pc), L.ptr(sc), sc.shape[0], L.ptr(gc), gc.numel(), int(grid_res),
+                                            L.ptr(out), L.stream_of(sc)), "nerf_occupancy_mask")
+        ctx.save_for_backward(pc, gc)
+        ctx.grid_res = int(grid_res)
+        return out.view(sigma.shape)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        pc, gc = ctx.saved_tensors
+        g = L.f32c(d_out).reshape(-1)
+        d_in = torch.empty_like(g)
+        L.check(L.lib().nerf_occupancy_mask(L.ptr(pc), L.ptr(g), g.shape[0], L.ptr(gc), gc.numel(), ctx.grid_res,
+                                            L.ptr(d_in), L.stream_of(g)), "nerf_occupancy_mask")
+        return d_in.view(d_out.shape), None, None, None
+
+
+def occupancy_mask(sigma, pts, grid, grid_res: int):
+    """Zero the densities of the samples ``pts`` that fall into empty cells of the uint8 occupancy ``grid``
+    (src/train_nerf_ngp.py:113-117)."""
+    return _OccupancyMask.apply(sigma, pts, grid, int(grid_res))
 
 
 # ---------------------------------------------------------- fused MLPs ----
@@ -276,7 +316,7 @@ class _VanillaMLP(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, dirs, dirs_div, skip_h_first, *params):
+    def forward(ctx, x, dirs, dirs_div, skip_h_first, grad_mode, *params):
         assert len(params) == 24
         L.need_gpu(x, dirs, *params)
         xc, dc = L.f32c(x.detach()), L.f32c(dirs.detach())
@@ -284,7 +324,9 @@ class _VanillaMLP(torch.autograd.Function):
         assert xc.shape == (P, 3), "x must be [N,3]"
         assert dc.shape == ((P + dirs_div - 1) // dirs_div, 3), "view_dirs must be [N,3] (or one row per ray)"
         packed = vanilla_pack(params, skip_h_first)
-        train = any(ctx.needs_input_grad[4:])
+        # needs_input_grad mirrors requires_grad even under no_grad, and grad mode is always off in here:
+        # the caller's grad mode arrives as an argument
+        train = grad_mode and any(ctx.needs_input_grad[5:])
         rgb, sigma, ws = vanilla_fwd_raw(xc, dc, dirs_div, packed, train)
         if train:
             ctx.save_for_backward(packed, rgb, sigma, ws)
@@ -299,15 +341,23 @@ class _VanillaMLP(torch.autograd.Function):
         dev = rgb.device
         grads = zero_grads_like(shapes, dev)
         if P == 0:
-            return (None, None, None, None, *grads)
+            return (None, None, None, None, None, *grads)
         d_rgb = L.f32c(d_rgb) if d_rgb is not None else torch.zeros(P, 3, device=dev)
         d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, 1, device=dev)
         vanilla_bwd_raw(d_rgb, d_sigma, packed, rgb, sigma, ws, vanilla_ws2(P, dev), skip, grads)
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 def vanilla_mlp(x, dirs, params, skip_h_first: bool, dirs_div: int = 1):
-    return _VanillaMLP.apply(x, dirs, int(dirs_div), bool(skip_h_first), *params)
+    return _VanillaMLP.apply(x, dirs, int(dirs_div), bool(skip_h_first), torch.is_grad_enabled(), *params)
+
+
+def vanilla_relu_masks(ws: torch.Tensor, P: int) -> torch.Tensor:
+    """uint8 [P, 2176]: which ReLUs of the forward pass that filled ``ws`` were open (8 x 256 trunk neurons,
+    then the 128 of the colour hidden layer) -- for parity checks."""
+    out = torch.empty(P, 2176, device=ws.device, dtype=torch.uint8)
+    L.check(L.lib().nerf_mlp_vanilla_relu_masks(L.ptr(ws), P, L.ptr(out), L.stream_of(ws)), "nerf_mlp_vanilla_relu_masks")
+    return out
 
 
 class _NgpMLP(torch.autograd.Function):
@@ -317,7 +367,7 @@ class _NgpMLP(torch.autograd.Function):
     skip_proj.weight.  Gradients go to the tables and the parameters."""
 
     @staticmethod
-    def forward(ctx, x, dirs, dirs_div, res, *tensors):
+    def forward(ctx, x, dirs, dirs_div, res, grad_mode, *tensors):
         tables, params = tensors[:16], tensors[16:]
         assert len(tables) == 16 and len(params) == 9
         L.need_gpu(x, dirs, *tensors)
@@ -335,7 +385,7 @@ class _NgpMLP(torch.autograd.Function):
         L.check(lib.nerf_mlp_ngp_pack(L.ptr_array(ps), L.ptr(packed), st), "nerf_mlp_ngp_pack")
         rgb = torch.empty(P, 3, device=dev)
         sigma = torch.empty(P, device=dev)
-        train = any(ctx.needs_input_grad[4:])
+        train = grad_mode and any(ctx.needs_input_grad[5:])   # see _VanillaMLP.forward
         ws = torch.empty(_ceil32(P) * lib.nerf_mlp_ngp_ws_floats_per_point(), device=dev) if train and P else None
         L.check(lib.nerf_mlp_ngp_fwd(L.ptr(xc), L.ptr(dc), int(dirs_div), P, L.ptr_array(tabs), L.int_array(res),
                                      L.int_array(sizes), L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), st),
@@ -354,7 +404,7 @@ class _NgpMLP(torch.autograd.Function):
         dev = rgb.device
         grads = zero_grads_like(shapes, dev)
         if P == 0:
-            return (None, None, None, None, *grads)
+            return (None, None, None, None, None, *grads)
         d_rgb = L.f32c(d_rgb) if d_rgb is not None else torch.zeros(P, 3, device=dev)
         d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, device=dev)
         ws2 = torch.empty(_ceil32(P) * lib.nerf_mlp_ngp_ws2_floats_per_point(), device=dev)
@@ -362,8 +412,33 @@ class _NgpMLP(torch.autograd.Function):
                                      L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(ws2),
                                      L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.stream_of(rgb)),
                 "nerf_mlp_ngp_bwd")
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 def ngp_mlp(x, dirs, tables, params, res, dirs_div: int = 1):
-    return _NgpMLP.apply(x, dirs, int(dirs_div), list(res), *tables, *params)
+    return _NgpMLP.apply(x, dirs, int(dirs_div), list(res), torch.is_grad_enabled(), *tables, *params)
+
+
+# ------------------------------------------------------------ optimiser ----
+def clip_grad_norm_(parameters, max_norm: float) -> torch.Tensor:
+    """torch.nn.utils.clip_grad_norm_ with the 2-norm (src/train_nerf.py:165) as three launches over all
+    gradients and no host round trip.  Returns the total norm as a 0-d device tensor."""
+    import ctypes as C
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.tensor(0.0)
+    L.need_gpu(*grads)
+    for g in grads:
+        if g.dtype != torch.float32 or not g.is_contiguous():
+            raise L.NerfHipError("clip_grad_norm_ needs contiguous float32 gradients")
+    lib = L.lib()
+    n = len(grads)
+    numel = (C.c_int64 * n)(*[g.numel() for g in grads])
+    dev = grads[0].device
+    work = torch.empty(lib.nerf_clip_grad_norm_workspace_floats(n, numel), device=dev)
+    total = torch.empty((), device=dev)
+    L.check(lib.nerf_clip_grad_norm(n, L.ptr_array(grads), numel, float(max_norm), L.ptr(work), L.ptr(total),
+                                    L.stream_of(grads[0])), "nerf_clip_grad_norm")
+    return total

@@ -4,8 +4,9 @@ Drop-in for the way the reference's training loops use ``torch.optim.Adam``
 (src/train_nerf_llff.py:82 ``Adam(lr=5e-4)``; src/train_nerf_ngp.py:55
 ``Adam(lr=1e-2, eps=1e-15)``): same constructor arguments for the options those
 loops use, same update rule, and a ``state_dict`` with torch's keys
-(``step`` / ``exp_avg`` / ``exp_avg_sq``), so checkpoints move both ways.
-Weight decay, amsgrad and maximize are not implemented and raise.
+(``step`` / ``exp_avg`` / ``exp_avg_sq``), so checkpoints move both ways.  ``weight_decay`` is torch's L2
+form (src/train_nerf_llff.py:82, src/train_nerf_skow.py:47 use 1e-6); amsgrad and maximize are
+not implemented and raise.  ``clip_grad_norm_`` (src/train_nerf.py:165) lives in ``nerf_amd.ops``.
 """
 from __future__ import annotations
 
@@ -19,11 +20,12 @@ from . import _lib as L
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  amsgrad: bool = False, maximize: bool = False):
-        if weight_decay != 0.0 or amsgrad or maximize:
-            raise NotImplementedError("FusedAdam implements plain Adam (no weight decay, amsgrad or maximize)")
-        if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+        if amsgrad or maximize:
+            raise NotImplementedError("FusedAdam implements Adam without amsgrad or maximize")
+        if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError("invalid Adam hyper-parameters")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0, amsgrad=False, maximize=False))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False,
+                                      maximize=False))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -57,7 +59,8 @@ class FusedAdam(torch.optim.Optimizer):
                 L.check(L.lib().nerf_adam_step(
                     n, L.ptr_array(plist), L.ptr_array(grads), L.ptr_array([self.state[p]["exp_avg"] for p in plist]),
                     L.ptr_array([self.state[p]["exp_avg_sq"] for p in plist]), numel, step0 + 1, group["lr"],
-                    group["betas"][0], group["betas"][1], group["eps"], L.stream_of(plist[0])), "nerf_adam_step")
+                    group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
+                    L.stream_of(plist[0])), "nerf_adam_step")
                 for p in plist:
                     self.state[p]["step"] += 1
         return loss

@@ -31,9 +31,17 @@ def _eval_model(model, pts, view_dirs, n_per_ray):
     return rgb.view(R, N, 3), sigma.reshape(R, N)
 
 
+def _linspace(near: float, far: float, n: int, dev) -> torch.Tensor:
+    """torch.linspace(near, far, n) exactly as the reference's CPU call computes it (src/Camera.py:130): the
+    GPU kernel of linspace rounds differently in places, and the depths are held to bit equality."""
+    return torch.linspace(near, far, n).to(dev)
+
+
 def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, perturb: bool = True,
                 t_rand: Optional[torch.Tensor] = None, white_bkgd: bool = False, fine_model=None,
-                n_importance: int = 0, u_fine: Optional[torch.Tensor] = None):
+                n_importance: int = 0, u_fine: Optional[torch.Tensor] = None, ndc=None,
+                density_grid: Optional[torch.Tensor] = None, grid_res: Optional[int] = None,
+                z_lin: Optional[torch.Tensor] = None, samples=None):
     """Render a batch of rays [R,3].
 
     Returns a dict with ``rgb`` [R,3], ``weights`` [R,N], ``z_vals`` [R,N],
@@ -41,15 +49,35 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
     ``rgb_fine``, ``weights_fine``, ``z_fine`` (the merged, sorted depths) and
     ``depth_fine``.  ``t_rand`` [R,N] / ``u_fine`` [R,n_importance] inject the
     uniform draws (drawn on the GPU when omitted).
+
+    ``ndc = (H, W, focal, near_plane)`` renders a forward-facing scene in normalised device coordinates
+    (NeRF 2020, appendix C; not in the reference): the rays are moved to the near plane and projected,
+    ``near``/``far`` are then NDC depths (0 and 1), the view directions fed to the model stay the
+    normalised world-space directions, and the compositor keeps ``Camera.volume_render``'s convention
+    of distances in depth units (not scaled by the length of the NDC direction).
+    ``density_grid`` (uint8, from ``get_density_grid``) zeroes the densities of samples in empty cells
+    before compositing, as the hash-grid training render does (src/train_nerf_ngp.py:113-117).
+    ``samples = (z_vals [R,N], pts [R,N,3])`` supplies coarse samples already drawn (by the fused
+    ``ops.raygen_sample``), in which case ``t_rand`` / ``perturb`` / ``z_lin`` are not used.
     """
     R = rays_o.shape[0]
     dev = rays_o.device
-    z_lin = torch.linspace(near, far, n_samples, device=dev)
-    if perturb and t_rand is None:
-        t_rand = torch.rand(R, n_samples, device=dev)
-    z, pts = ops.stratified_sample(rays_o, rays_d, z_lin, t_rand if perturb else None)
     view_dirs = rays_d / rays_d.norm(dim=-1, keepdim=True)   # as render_image does (src/train_nerf_llff.py:42)
+    if ndc is not None:
+        H, W, focal, near_plane = ndc
+        rays_o, rays_d = ops.ndc_rays(int(H), int(W), float(focal), float(near_plane), rays_o, rays_d)
+    if samples is not None:
+        assert ndc is None, "samples drawn along world-space rays do not fit an NDC render"
+        z, pts = samples
+    else:
+        if z_lin is None:
+            z_lin = _linspace(near, far, n_samples, dev)
+        if perturb and t_rand is None:
+            t_rand = torch.rand(R, n_samples, device=dev)
+        z, pts = ops.stratified_sample(rays_o, rays_d, z_lin, t_rand if perturb else None)
     rgb, sigma = _eval_model(model, pts, view_dirs, n_samples)
+    if density_grid is not None:
+        sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
     c_map, w, depth = ops.composite(rgb, sigma, z, white_bkgd)
     out = {"rgb": c_map, "weights": w, "z_vals": z, "depth": depth}
     if fine_model is not None and n_importance > 0:
@@ -57,9 +85,68 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
             u_fine = torch.rand(R, n_importance, device=dev)
         _, _, z_all, pts_f = ops.pdf_sample(rays_o, rays_d, z, w, u_fine)
         rgb_f, sigma_f = _eval_model(fine_model, pts_f, view_dirs, n_samples + n_importance)
+        if density_grid is not None:
+            sigma_f = ops.occupancy_mask(sigma_f, pts_f, density_grid, grid_res)
         f_map, w_f, depth_f = ops.composite(rgb_f, sigma_f, z_all, white_bkgd)
         out.update({"rgb_fine": f_map, "weights_fine": w_f, "z_fine": z_all, "depth_fine": depth_f})
     return out
+
+
+def workspace_bytes_per_ray(model, n_samples: int, fine_model=None, n_importance: int = 0) -> int:
+    """Bytes of activation workspace a training render keeps per ray (forward workspaces of both passes
+    plus the larger backward scratch)."""
+    from . import _lib as L
+    lib = L.lib()
+
+    def per_point(m):
+        if hasattr(m, "_tables"):
+            return lib.nerf_mlp_ngp_ws_floats_per_point(), lib.nerf_mlp_ngp_ws2_floats_per_point()
+        return lib.nerf_mlp_vanilla_ws_floats_per_point(), lib.nerf_mlp_vanilla_ws2_floats_per_point()
+
+    ws, ws2 = per_point(model)
+    floats, scratch = ws * n_samples, ws2 * n_samples
+    if fine_model is not None and n_importance > 0:
+        ws_f, ws2_f = per_point(fine_model)
+        floats += ws_f * (n_samples + n_importance)
+        scratch = max(scratch, ws2_f * (n_samples + n_importance))
+    return 4 * (floats + scratch)
+
+
+def train_step(model, rays_o, rays_d, target, near: float, far: float, n_samples: int, *, loss_fn=None,
+               chunk_rays: Optional[int] = None, workspace_budget: int = 32 << 30, buckets=None,
+               grad_scale: Optional[float] = None, t_rand: Optional[torch.Tensor] = None,
+               u_fine: Optional[torch.Tensor] = None, samples=None, **render_kw) -> torch.Tensor:
+    """Forward + backward of one training step over R rays, in ray chunks, gradients accumulated.
+
+    The reference bounds memory with a chunk loop over points inside ``render_image``
+    (src/train_nerf_llff.py:50-56) while autograd still keeps every chunk's activations; here a chunk of
+    rays runs forward AND backward before the next one starts, so the activation workspace (20 KB per
+    point evaluation of the 8x256 MLP) is bounded by ``chunk_rays`` whatever R is -- 65,536 rays x (64 + 192)
+    evaluations would need 300 GB otherwise.  ``chunk_rays`` defaults to the largest power of two whose
+    workspace fits ``workspace_budget`` bytes.
+
+    ``loss_fn(out, target_chunk)`` must be a mean over rays (default: ``nerf_loss``).  ``buckets`` (a
+    ``nerf_amd.dist.GradBuckets``) receives the gradients in its flat buffers and overlaps the cross-rank
+    sum with the last chunk's backward; without it the gradients accumulate into ``p.grad`` (zero them
+    first).  The optimiser step is the caller's.  Returns the detached loss (0-d tensor).
+    """
+    from .dist import accumulate_step
+    R = rays_o.shape[0]
+    loss_fn = loss_fn or nerf_loss
+    if chunk_rays is None:
+        per_ray = workspace_bytes_per_ray(model, n_samples, render_kw.get("fine_model"), render_kw.get("n_importance", 0))
+        chunk_rays = 1 << max(0, (workspace_budget // max(per_ray, 1)).bit_length() - 1)
+    chunk_rays = max(1, min(int(chunk_rays), R))
+    z_lin = _linspace(near, far, n_samples, rays_o.device) if samples is None else None
+
+    def loss_of_chunk(lo, hi):
+        out = render_rays(model, rays_o[lo:hi], rays_d[lo:hi], near, far, n_samples,
+                          t_rand=None if t_rand is None else t_rand[lo:hi],
+                          u_fine=None if u_fine is None else u_fine[lo:hi], z_lin=z_lin,
+                          samples=None if samples is None else (samples[0][lo:hi], samples[1][lo:hi]), **render_kw)
+        return loss_fn(out, target[lo:hi])
+
+    return accumulate_step(R, chunk_rays, loss_of_chunk, buckets, grad_scale)
 
 
 def xyz_to_idx(x, y, z, res: int = 32):
@@ -85,14 +172,15 @@ def get_density_grid(model, device, grid_res: int):
 
 def render_image(model, rays_o, rays_d, near: float, far: float, n_samples: int = 64, grid_res: Optional[int] = None,
                  density_grid: Optional[torch.Tensor] = None, white_bkgd: bool = False, fine_model=None,
-                 n_importance: int = 0, rays_per_tile: int = 65536, return_depth: bool = False):
+                 n_importance: int = 0, rays_per_tile: int = 65536, return_depth: bool = False, ndc=None):
     """Full-image inference: rays [H,W,3] -> colour map [H,W,3] (and depth [H,W]).
 
     The counterpart of ``render_from_model`` (src/utils/analyze_capture_results.py:250-296): unperturbed
     samples, no autograd, sigma zeroed outside the occupancy grid when one is given.  The reference
     materialises all H*W*N points and loops over 16384-point chunks of them; here the loop is over tiles
     of rays and each tile runs sample -> model -> composite end to end.  With ``fine_model`` a second,
-    importance-sampled pass follows (deterministic: evenly spaced CDF positions).
+    importance-sampled pass follows (deterministic: evenly spaced CDF positions).  ``ndc`` as in
+    ``render_rays``.
     """
     H, W = rays_o.shape[0], rays_o.shape[1]
     o_all, d_all = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
@@ -100,39 +188,30 @@ def render_image(model, rays_o, rays_d, near: float, far: float, n_samples: int 
     dev = o_all.device
     out = torch.empty(R, 3, device=dev)
     depth = torch.empty(R, device=dev) if return_depth else None
-    z_lin = torch.linspace(near, far, n_samples, device=dev)
+    z_lin = _linspace(near, far, n_samples, dev)
     with torch.no_grad():
         for r0 in range(0, R, rays_per_tile):
             o, d = o_all[r0:r0 + rays_per_tile], d_all[r0:r0 + rays_per_tile]
-            z, pts = ops.stratified_sample(o, d, z_lin, None)
             view_dirs = d / d.norm(dim=-1, keepdim=True)
+            if ndc is not None:
+                o, d = ops.ndc_rays(int(ndc[0]), int(ndc[1]), float(ndc[2]), float(ndc[3]), o, d)
+            z, pts = ops.stratified_sample(o, d, z_lin, None)
             rgb, sigma = _eval_model(model, pts, view_dirs, n_samples)
             if density_grid is not None:
-                sigma = _mask_sigma(sigma, pts, grid_res, density_grid)
+                sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
             c_map, w, dep = ops.composite(rgb, sigma, z, white_bkgd)
             if fine_model is not None and n_importance > 0:
                 u = torch.linspace(0.0, 1.0, n_importance, device=dev).expand(o.shape[0], n_importance).contiguous()
                 _, _, z, pts = ops.pdf_sample(o, d, z, w, u)
                 rgb, sigma = _eval_model(fine_model, pts, view_dirs, n_samples + n_importance)
                 if density_grid is not None:
-                    sigma = _mask_sigma(sigma, pts, grid_res, density_grid)
+                    sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
                 c_map, w, dep = ops.composite(rgb, sigma, z, white_bkgd)
             out[r0:r0 + rays_per_tile] = c_map
             if return_depth:
                 depth[r0:r0 + rays_per_tile] = dep
     img = out.view(H, W, 3)
     return (img, depth.view(H, W)) if return_depth else img
-
-
-def _mask_sigma(sigma, pts, grid_res, density_grid):
-    """sigma with the samples in empty occupancy cells zeroed (src/utils/analyze_capture_results.py:284-288)."""
-    cell = 1.0 / grid_res
-    x, y, z = ((pts.reshape(-1, 3) + 1) / 2 / cell).long().T.unbind(0)
-    # samples outside [-1, 1)^3 index past the grid in the reference (an IndexError there); they are
-    # clamped to the nearest stored cell here, since a device-side index fault would end the process
-    idx = xyz_to_idx(x, y, z).clamp_(0, density_grid.numel() - 1)
-    keep = density_grid[idx] == 1
-    return torch.where(keep.view(sigma.shape), sigma, torch.zeros_like(sigma))
 
 
 def render_image_sharded(model, rays_o, rays_d, near: float, far: float, group=None, **kw):

@@ -2,7 +2,7 @@
 
 Run only in the development container, where the reference checkout exists:
 
-    MPLBACKEND=Agg python oracle/gen_golden.py [/root/reference]
+    MPLBACKEND=Agg python oracle/gen_golden.py [/root/reference [g1 g2 ... g9]]
 
 The outputs are small input/output vectors of the reference's own functions
 (plus per-parameter checksums proving that seeded construction gives the same
@@ -287,12 +287,113 @@ def g7():
          cfg=np.array([H, W, 30.0, 1.0, 5.0, n]))
 
 
+# ---------------------------------------------------------------- G8 the older free functions
+def g8():
+    """src/utils/get_rays.py: compute_stable_up, look_at_camera, get_rays ([W,H,3], +z forward),
+    sample_points_along_rays (no perturbation), volume_render (1e10 tail) and the three analytic fields."""
+    import contextlib
+    import io
+    eye, tgt = torch.tensor([2.0, -1.5, 1.0]), torch.tensor([0.1, 0.2, 0.0])
+    up = legacy.compute_stable_up(eye, tgt)
+    up_vert = legacy.compute_stable_up(torch.tensor([0.0, -3.0, 0.0]), torch.tensor([0.0, 0.0, 0.0]))
+    c2w = legacy.look_at_camera(eye, tgt, up)
+    H, W, focal = 12, 20, 25.0
+    ro, rd = legacy.get_rays(H, W, focal, c2w)
+    pts, z = legacy.sample_points_along_rays(ro, rd, 1.0, 5.0, 16)
+    out = dict(eye=eye, tgt=tgt, up=up, up_vert=up_vert, c2w=c2w, hwf=np.array([H, W, focal]), rays_o=ro.contiguous(),
+               rays_d=rd, pts=pts, z=z.contiguous(), cfg=np.array([1.0, 5.0, 16]))
+    for name in ("complex", "sphere", "torus"):
+        rgb, sigma = getattr(legacy, "evaluate_fake_radiance_field_" + name)(pts)
+        with contextlib.redirect_stdout(io.StringIO()):
+            img = legacy.volume_render(rgb.contiguous(), sigma, z)
+        out.update({f"{name}_rgb": rgb.contiguous(), f"{name}_sigma": sigma, f"{name}_img": img})
+    save("g8_legacy.npz", **out)
+
+
+# ---------------------------------------------------------------- G9 training trajectory, 100x100 / 64 samples
+def g9(steps=320):
+    """The reference's own pieces trained on the analytic scene at the size of its synthetic trainer
+    (src/train_nerf.py:91-92: 100 x 100 rays, 64 samples; 40 views on a circle, :53-54): NeRF() from
+    torch.manual_seed(0), Camera.sample_points_along_rays(perturb=True) under torch.manual_seed(1000 + step),
+    chunked model calls, Camera.volume_render, mse_loss, clip_grad_norm_(1.0) (:165), Adam(lr=5e-4) (:86).
+    Recorded: loss of every step, PSNR of a held-out view at a few step counts.  The ground-truth images are
+    not stored (the far side re-renders the analytic field); their checksums are."""
+    import time
+    H = W = 100
+    n, near, far, boost = 64, 1.0, 5.0, 5.0
+    focal = (100.0, 100.0)
+    up = torch.tensor([0.0, 0.0, 1.0])
+
+    def pose(ang, height):
+        eye = torch.tensor([2.0 * np.cos(ang), 2.0 * np.sin(ang), height], dtype=torch.float32)
+        # look-at cameras face away from their target (rays go along -forward): aim at the mirrored point
+        return Camera(eye=eye, target=2 * eye, focal=focal, H=H, W=W, up=up)
+
+    cams = [pose(float(a), 2.0) for a in torch.linspace(0, 2 * torch.pi, steps=40)] + [pose(0.7, 1.5)]
+    rays, imgs = [], []
+    for cam in cams:
+        ro, rd = cam.get_rays()
+        pts, z = Camera.sample_points_along_rays(ro, rd, near, far, n, perturb=False)
+        rgb, sigma = legacy.evaluate_fake_radiance_field_complex(pts)
+        img, _ = Camera.volume_render(rgb, sigma * boost, z)
+        rays.append((ro, rd))
+        imgs.append(img)
+
+    def run_model(model, pts, dirs, chunk=65536):
+        rgbs, sigmas = [], []
+        for i in range(0, pts.shape[0], chunk):
+            r, s = model(pts[i:i + chunk], dirs[i:i + chunk])
+            rgbs.append(r)
+            sigmas.append(s)
+        return torch.cat(rgbs), torch.cat(sigmas)
+
+    def render(model, ro, rd, perturb):
+        pts, z = Camera.sample_points_along_rays(ro, rd, near, far, n, perturb=perturb)
+        vd = (rd / rd.norm(dim=-1, keepdim=True))[:, :, None, :].expand(H, W, n, 3)
+        rgb, sigma = run_model(model, pts.reshape(-1, 3), vd.reshape(-1, 3))
+        return Camera.volume_render(rgb.view(H, W, n, 3), sigma.view(H, W, n), z)[0]
+
+    def psnr(x, y):
+        return float(-10.0 * torch.log10(torch.mean((x - y) ** 2)))
+
+    import contextlib
+    import io
+    torch.manual_seed(0)
+    model = NeRF()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    losses, norms, marks, psnrs = [], [], [], []
+    t0 = time.time()
+    for step in range(steps):
+        v = step % 40
+        torch.manual_seed(1000 + step)
+        with contextlib.redirect_stdout(io.StringIO()):   # NeRF.forward prints on NaN
+            img = render(model, rays[v][0], rays[v][1], True)
+        loss = torch.nn.functional.mse_loss(img, imgs[v])
+        opt.zero_grad()
+        loss.backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)))
+        opt.step()
+        losses.append(float(loss.detach()))
+        if (step + 1) in (40, 80, 160, 240, steps):
+            with torch.no_grad():
+                held = render(model, rays[40][0], rays[40][1], False)
+            marks.append(step + 1)
+            psnrs.append(psnr(held, imgs[40]))
+            print(f"step {step + 1}: loss {losses[-1]:.6f} held-out psnr {psnrs[-1]:.3f} ({time.time() - t0:.0f}s)", flush=True)
+    save("g9_train.npz", c2w=torch.stack([c.c2w for c in cams]), cfg=np.array([H, W, focal[0], near, far, n, boost]),
+         img_sum=np.array([float(i.double().sum()) for i in imgs]), img_sample=torch.stack([i[::10, ::10] for i in imgs]),
+         loss=np.array(losses), grad_norm=np.array(norms), psnr_steps=np.array(marks), psnr=np.array(psnrs))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    o1 = g1()
-    o2 = g2(o1)
-    g3()
-    g4()
-    g5()
-    g6(o2)
-    g7()
+    which = [a for a in sys.argv[2:]] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]   # g9 takes ~40 min: by name only
+    o1 = g1() if {"g1", "g2", "g6"} & set(which) else None
+    o2 = g2(o1) if {"g2", "g6"} & set(which) else None
+    if "g3" in which: g3()
+    if "g4" in which: g4()
+    if "g5" in which: g5()
+    if "g6" in which: g6(o2)
+    if "g7" in which: g7()
+    if "g8" in which: g8()
+    if "g9" in which: g9()

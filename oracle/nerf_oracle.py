@@ -104,15 +104,16 @@ def sample_points_along_rays(rays_o, rays_d, near, far, n_samples,
     return pts, z
 
 
-def volume_render(rgb, sigma, z_vals, white_bkgd: bool = False):
+def volume_render(rgb, sigma, z_vals, white_bkgd: bool = False, tail: float = 1e5):
     """Alpha compositing, src/Camera.py:143-183.
 
     delta_i = z_{i+1}-z_i with a 1e5 tail, alpha = 1-exp(-sigma*delta),
     T_i = prod_{j<i}(1-alpha_j+1e-10), w = alpha*T, C = sum w c
-    (+ 1 - sum w when white_bkgd).
+    (+ 1 - sum w when white_bkgd).  The older free function (src/utils/get_rays.py:198-236)
+    is the same with tail = 1e10 and only the colour returned.
     """
     dists = z_vals[..., 1:] - z_vals[..., :-1]
-    dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e5)], dim=-1)
+    dists = torch.cat([dists, torch.full_like(dists[..., :1], tail)], dim=-1)
     alpha = 1.0 - torch.exp(-sigma * dists)
     trans = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1.0 - alpha + 1e-10], dim=-1),
                           dim=-1)[..., :-1]
@@ -121,6 +122,60 @@ def volume_render(rgb, sigma, z_vals, white_bkgd: bool = False):
     if white_bkgd:
         out = out + (1.0 - weights.sum(dim=-1, keepdim=True))
     return out, weights
+
+
+# The older free functions of src/utils/get_rays.py (another camera convention).
+
+
+def legacy_compute_stable_up(eye, target):
+    """src/utils/get_rays.py:6-19."""
+    fwd = target - eye
+    fwd = fwd / torch.norm(fwd)
+    guess = torch.tensor([0.0, 1.0, 0.0])
+    if torch.allclose(fwd, guess, atol=1e-2) or torch.allclose(fwd, -guess, atol=1e-2):
+        guess = torch.tensor([0.0, 0.0, 1.0])
+    proj = guess - torch.dot(guess, fwd) * fwd
+    return proj / torch.norm(proj)
+
+
+def legacy_look_at_camera(eye, target, up):
+    """src/utils/get_rays.py:151-170: right = forward x up, true_up = right x forward."""
+    fwd = target - eye
+    fwd = fwd / torch.norm(fwd)
+    right = torch.linalg.cross(fwd, up)
+    right = right / torch.norm(right)
+    true_up = torch.linalg.cross(right, fwd)
+    return torch.cat([torch.stack([right, true_up, fwd], dim=1), eye.view(3, 1)], dim=1)
+
+
+def legacy_get_rays(H: int, W: int, focal: float, c2w: torch.Tensor):
+    """src/utils/get_rays.py:115-147: [W,H,3] outputs (the meshgrid runs over the width first), camera
+    looking along +z, principal point at the image centre."""
+    i, j = torch.meshgrid(torch.arange(W, dtype=torch.float32), torch.arange(H, dtype=torch.float32), indexing="ij")
+    d_cam = torch.stack([(i - W * 0.5) / focal, -(j - H * 0.5) / focal, torch.ones_like(i)], dim=-1)
+    rays_d = torch.sum(d_cam[..., None, :] * c2w[:3, :3], dim=-1)
+    rays_d = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    return c2w[:3, 3].expand_as(rays_d), rays_d
+
+
+def legacy_volume_render(rgb, sigma, z_vals):
+    """src/utils/get_rays.py:198-236 (without its prints)."""
+    return volume_render(rgb, sigma, z_vals, tail=1e10)[0]
+
+
+def analytic_field_sphere(pts):
+    """src/utils/get_rays.py:67-86: red unit ball of density 50."""
+    rgb = torch.zeros_like(pts)
+    rgb[..., 0] = 1.0
+    return rgb, (torch.norm(pts, dim=-1) < 1.0).to(pts.dtype) * 50.0
+
+
+def analytic_field_torus(pts):
+    """src/utils/get_rays.py:88-112: hard red torus in the xz plane."""
+    x, y, z = pts[..., 0], pts[..., 1], pts[..., 2]
+    rgb = torch.zeros_like(pts)
+    rgb[..., 0] = 1.0
+    return rgb, (((torch.sqrt(x ** 2 + z ** 2) - 1.2) ** 2 + y ** 2) < 0.3 ** 2).float() * 5.0
 
 
 def depth(weights, z_vals):
@@ -226,18 +281,32 @@ class NeRFOracle(nn.Module):
         self.rgb_layers = nn.Sequential(nn.Linear(hidden_dim + in_dir, hidden_dim // 2), nn.ReLU(),
                                         nn.Linear(hidden_dim // 2, 3), nn.Sigmoid())
 
-    def forward(self, x, view_dirs):
+    def forward(self, x, view_dirs, masks=None, record=None):
+        """``masks`` (bool/0-1 [P, 8*256 + 128], trunk layers then the colour hidden layer) replaces every
+        ReLU by a multiplication with the given pattern: the network becomes the piecewise-linear branch
+        another implementation took, so gradients can be compared without ReLUs whose pre-activation is
+        within rounding of zero flipping.  ``record``: a list that receives every pre-activation."""
         xe = positional_encoding(x, self.xyz_freqs)
         h = xe
         for i, lin in enumerate(self.layers_xyz):
             if i in self.skips:
                 h = torch.cat([xe, h], dim=-1)
-            h = F.relu(lin(h))
+            pre = lin(h)
+            if record is not None:
+                record.append(pre.detach())
+            h = F.relu(pre) if masks is None else pre * masks[:, 256 * i:256 * (i + 1)].to(pre.dtype)
         sigma = F.softplus(self.sigma_out(h))
         if view_dirs is None:
             return torch.zeros(x.shape[0], 3), sigma
         de = positional_encoding(view_dirs, self.dir_freqs)
-        rgb = self.rgb_layers(torch.cat([self.feature_layer(h), de], dim=-1))
+        if masks is None and record is None:
+            rgb = self.rgb_layers(torch.cat([self.feature_layer(h), de], dim=-1))
+        else:
+            pre = self.rgb_layers[0](torch.cat([self.feature_layer(h), de], dim=-1))
+            if record is not None:
+                record.append(pre.detach())
+            hr = F.relu(pre) if masks is None else pre * masks[:, 2048:2176].to(pre.dtype)
+            rgb = torch.sigmoid(self.rgb_layers[2](hr))
         return rgb, sigma
 
 
@@ -401,35 +470,80 @@ def ndc_rays(H: int, W: int, focal: float, near: float, rays_o, rays_d):
 # --------------------------------------------------------------------------
 
 
-def run_model_chunked(model, pts, dirs, chunk):
+def run_model_chunked(model, pts, dirs, chunk, masks=None):
     """Chunk loop of src/train_nerf_llff.py:31-64 / src/train_nerf_ngp.py:80-126."""
     rgbs, sigmas = [], []
     for i in range(0, pts.shape[0], chunk):
-        r, s = model(pts[i:i + chunk], dirs[i:i + chunk])
+        if masks is None:
+            r, s = model(pts[i:i + chunk], dirs[i:i + chunk])
+        else:
+            r, s = model(pts[i:i + chunk], dirs[i:i + chunk], masks=masks[i:i + chunk])
         rgbs.append(r)
         sigmas.append(s)
     return torch.cat(rgbs, 0), torch.cat(sigmas, 0)
 
 
+def xyz_to_idx(x, y, z, res: int = 32):
+    """src/utils/analyze_capture_results.py:230-231 (callers never pass res)."""
+    return x + y * res + z * res * res
+
+
+def occupancy_mask(sigma, pts, density_grid, grid_res: int):
+    """sigma with the samples in empty occupancy cells zeroed, src/train_nerf_ngp.py:113-117 (torch.where in
+    place of the in-place write: same values, same zero gradient).  A cell index past the grid, an
+    IndexError in the reference, is clamped (the HIP kernel does the same)."""
+    cell = 1.0 / grid_res
+    x, y, z = ((pts.reshape(-1, 3) + 1) / 2 / cell).long().T.unbind(0)
+    idx = xyz_to_idx(x, y, z).clamp(0, density_grid.numel() - 1)
+    keep = (density_grid[idx] == 1).view(sigma.shape)
+    return torch.where(keep, sigma, torch.zeros_like(sigma))
+
+
+def get_density_grid(model, grid_res: int):
+    """src/utils/analyze_capture_results.py:233-248: lattice points of [-1,1]^3 whose density exceeds 1."""
+    r = torch.arange(grid_res)
+    coords = torch.stack(torch.meshgrid(r, r, r, indexing="ij"), dim=-1).view(-1, 3)
+    grid = torch.zeros(grid_res ** 3, dtype=torch.uint8)
+    with torch.no_grad():
+        for i in range(0, coords.shape[0], 65536):
+            c = coords[i:i + 65536]
+            mask = model.query_density((c.float() / (grid_res - 1)) * 2 - 1) > 1.0
+            grid[xyz_to_idx(c[:, 0], c[:, 1], c[:, 2])] |= mask.to(torch.uint8)
+    return grid
+
+
 def render_rays(model, rays_o, rays_d, near, far, n_samples, t_rand=None, chunk=2048,
-                white_bkgd=False, fine_model=None, u_fine=None):
+                white_bkgd=False, fine_model=None, u_fine=None, ndc=None, density_grid=None, grid_res=None,
+                masks=None, masks_fine=None, z_fixed=None):
     """rays [R,3] -> colour [R,3] (and the fine-pass colour when fine_model is
     given).  Coarse pass = the reference's render_image; the fine pass is the
-    build-defined hierarchical stage."""
+    build-defined hierarchical stage.  ndc = (H, W, focal, near_plane): forward-facing NDC rays
+    (view directions stay the normalised world directions; distances stay depth differences).
+    density_grid: occupancy masking of sigma before compositing (src/train_nerf_ngp.py:113-117).
+    masks / masks_fine: forced ReLU patterns (NeRFOracle.forward); z_fixed: the merged fine-pass depths to use
+    instead of this function's own inverse-CDF result (so that both sides evaluate the same points)."""
     R = rays_o.shape[0]
-    pts, z = sample_points_along_rays(rays_o, rays_d, near, far, n_samples, t_rand)
     vd = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    if ndc is not None:
+        rays_o, rays_d = ndc_rays(int(ndc[0]), int(ndc[1]), float(ndc[2]), float(ndc[3]), rays_o, rays_d)
+    pts, z = sample_points_along_rays(rays_o, rays_d, near, far, n_samples, t_rand)
     dirs = vd[:, None, :].expand_as(pts).reshape(-1, 3)
-    rgb, sigma = run_model_chunked(model, pts.reshape(-1, 3), dirs, chunk)
-    c_map, w = volume_render(rgb.view(R, n_samples, 3), sigma.view(R, n_samples), z, white_bkgd)
+    rgb, sigma = run_model_chunked(model, pts.reshape(-1, 3), dirs, chunk, masks)
+    sigma = sigma.view(R, n_samples)
+    if density_grid is not None:
+        sigma = occupancy_mask(sigma, pts, density_grid, grid_res)
+    c_map, w = volume_render(rgb.view(R, n_samples, 3), sigma, z, white_bkgd)
     if fine_model is None:
         return c_map, w, z, None
-    _, _, z_all = sample_pdf(z, w.detach(), u_fine)
+    z_all = sample_pdf(z, w.detach(), u_fine)[2] if z_fixed is None else z_fixed
     nf = z_all.shape[-1]
     pts_f = rays_o[:, None, :] + rays_d[:, None, :] * z_all[..., None]
     dirs_f = vd[:, None, :].expand_as(pts_f).reshape(-1, 3)
-    rgb_f, sigma_f = run_model_chunked(fine_model, pts_f.reshape(-1, 3), dirs_f, chunk)
-    f_map, w_f = volume_render(rgb_f.view(R, nf, 3), sigma_f.view(R, nf), z_all, white_bkgd)
+    rgb_f, sigma_f = run_model_chunked(fine_model, pts_f.reshape(-1, 3), dirs_f, chunk, masks_fine)
+    sigma_f = sigma_f.view(R, nf)
+    if density_grid is not None:
+        sigma_f = occupancy_mask(sigma_f, pts_f, density_grid, grid_res)
+    f_map, w_f = volume_render(rgb_f.view(R, nf, 3), sigma_f, z_all, white_bkgd)
     return c_map, w, z, (f_map, w_f, z_all)
 
 

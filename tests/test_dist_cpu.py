@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nerf_amd.dist import GradAverager, broadcast_parameters, gather_rows, shard_range
+from nerf_amd.dist import GradAverager, GradBuckets, accumulate_step, broadcast_parameters, gather_rows, shard_range
 
 
 def _free_port():
@@ -47,6 +47,76 @@ def _worker(rank, world, port, out):
         out[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
+
+
+def _chunked_worker(rank, world, port, out):
+    """The chunked training step (ray chunks, gradients accumulated in flat bucket buffers, one all-reduce per
+    bucket issued from the gradient hooks of the last chunk) against a single-process full-batch gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(7)
+        coarse = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 3))
+        fine = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.ReLU(), torch.nn.Linear(4, 3))
+        unused = torch.nn.Parameter(torch.ones(5))          # never reached by backward: finish() must still send it
+        buckets = GradBuckets([list(fine.parameters()), list(coarse.parameters()) + [unused]])
+        g = torch.Generator().manual_seed(5)
+        n_all = 46                                          # rays of the global batch; 23 per rank, chunks of 8 (ragged tail)
+        x_all, y_all = torch.randn(n_all, 6, generator=g), torch.randn(n_all, 3, generator=g)
+        b, e = shard_range(n_all, rank, world)
+        x, y = x_all[b:e], y_all[b:e]
+
+        def loss_of_chunk(lo, hi):                          # a mean over the chunk's rays, like nerf_loss
+            return torch.nn.functional.mse_loss(coarse(x[lo:hi]), y[lo:hi]) + torch.nn.functional.mse_loss(fine(x[lo:hi]), y[lo:hi])
+
+        ok = True
+        for step in range(2):                               # twice: the buffers and hooks are reused
+            loss = accumulate_step(e - b, 8, loss_of_chunk, buckets)
+            ptrs = [p.grad.data_ptr() for p in buckets.parameters()]
+            ok &= ptrs == [v.data_ptr() for views in buckets.views for v in views]   # accumulated in place
+            ref_c = torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 3))
+            ref_f = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.ReLU(), torch.nn.Linear(4, 3))
+            ref_c.load_state_dict(coarse.state_dict())
+            ref_f.load_state_dict(fine.state_dict())
+            full = torch.nn.functional.mse_loss(ref_c(x_all), y_all) + torch.nn.functional.mse_loss(ref_f(x_all), y_all)
+            full.backward()
+            for p, q in zip(list(fine.parameters()) + list(coarse.parameters()),
+                            list(ref_f.parameters()) + list(ref_c.parameters())):
+                ok &= torch.allclose(p.grad, q.grad, atol=1e-6)
+            ok &= float(unused.grad.abs().sum()) == 0.0
+            # the per-rank losses average to the full-batch loss (equal shard sizes)
+            t = loss.clone()
+            dist.all_reduce(t)
+            ok &= abs(float(t) / world - float(full)) < 1e-5
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_step_with_bucketed_allreduce_two_ranks():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_chunked_worker, args=(world, port, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+def test_grad_buckets_single_process():
+    """World size 1 (no process group): flat storage, in-place accumulation over chunks, no exchange."""
+    torch.manual_seed(1)
+    m = torch.nn.Linear(4, 2)
+    gb = GradBuckets(list(m.parameters()))
+    x, y = torch.randn(10, 4), torch.randn(10, 2)
+    loss = accumulate_step(10, 3, lambda lo, hi: torch.nn.functional.mse_loss(m(x[lo:hi]), y[lo:hi]), gb)
+    ref = torch.nn.Linear(4, 2)
+    ref.load_state_dict(m.state_dict())
+    full = torch.nn.functional.mse_loss(ref(x), y)
+    full.backward()
+    assert abs(float(loss) - float(full)) < 1e-6
+    for p, q in zip(m.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6)
+    assert m.weight.grad.data_ptr() == gb.flats[0].data_ptr()
 
 
 def test_shard_range_covers_everything():

@@ -18,11 +18,10 @@ def _scene(n=7, H=24, W=40, seed=0):
     return poses, intr, images
 
 
-def test_raygen_multi_matches_per_camera_raygen_and_oracle():
+def test_raygen_multi_matches_per_camera_raygen_and_oracle(dev):
     from nerf_amd import ops
     from nerf_amd.data.ray_buffer import camera_rows
     from oracle import nerf_oracle as O
-    dev = torch.device("cuda:0")
     poses, intr, images = _scene()
     n, H, W = images.shape[:3]
     g = torch.Generator().manual_seed(1)
@@ -46,9 +45,8 @@ def test_raygen_multi_matches_per_camera_raygen_and_oracle():
     assert e[0].shape == (0, 3)
 
 
-def test_ray_buffer_epoch_covers_every_pixel_once_across_ranks():
+def test_ray_buffer_epoch_covers_every_pixel_once_across_ranks(dev):
     from nerf_amd.data import RayBuffer
-    dev = torch.device("cuda:0")
     poses, intr, images = _scene(n=3, H=8, W=16)
     total = 3 * 8 * 16
     seen = []
@@ -64,3 +62,21 @@ def test_ray_buffer_epoch_covers_every_pixel_once_across_ranks():
     allpix = images.view(-1, 3)
     b = allpix[np.lexsort(allpix.numpy().T[::-1])]
     assert torch.equal(a, b)
+
+
+def test_out_of_range_ids_give_nan_rays_not_faults(dev):
+    """A camera or pixel id outside its range reads nothing and comes back as NaN."""
+    from nerf_amd import ops
+    cams = torch.zeros(2, 16)
+    cams[:, 0] = cams[:, 5] = cams[:, 10] = 1.0
+    cams[:, 12:] = torch.tensor([50.0, 50.0, 4.0, 3.0])
+    H, W = 6, 8
+    images = torch.rand(2, H, W, 3)
+    cam_id = torch.tensor([0, 1, 2, -1, 1, 0], dtype=torch.int32)
+    pix = torch.tensor([0, 47, 5, 5, 48, -3], dtype=torch.int32)
+    o, d, rgb = ops.raygen_multi(cams.to(dev), H, W, cam_id.to(dev), pix.to(dev), images.to(dev))
+    bad = torch.tensor([False, False, True, True, True, True])
+    assert torch.isnan(d.cpu()[bad]).all() and torch.isnan(rgb.cpu()[bad]).all() and torch.isnan(o.cpu()[bad]).all()
+    assert torch.isfinite(d.cpu()[~bad]).all() and torch.equal(rgb.cpu()[1], images[1].reshape(-1, 3)[47])
+    o1, d1 = ops.raygen(torch.eye(4)[:3].to(dev), 50.0, 50.0, 4.0, 3.0, H, W, torch.tensor([0, 48, -1], dtype=torch.int32).to(dev))
+    assert torch.isfinite(d1.cpu()[0]).all() and torch.isnan(d1.cpu()[1:]).all()

@@ -158,3 +158,271 @@ def test_psnr_after_fixed_steps_matches_cpu_training(dev):
     assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-3 * max(1e-3, float(loss_ref.detach())) + 1e-5
     assert abs(psnr - psnr_ref) < 0.1, (psnr, psnr_ref)
     assert psnr > float(O.psnr(torch.zeros_like(gt), gt)) - 3.0   # training did not diverge
+
+
+# --------------------------------------------------------------------------------------------------
+# The 1e-3 gradient contract in a well-posed form.  A whole render puts its gradient mass on a few samples,
+# so a ReLU whose pre-activation is within rounding of zero -- open in one float32 implementation, shut in
+# another -- moves a trunk gradient by more than 1e-3.  The forward pass records which ReLUs it found open;
+# the oracle is evaluated on exactly that piecewise-linear branch, and the few disagreements with the
+# oracle's own pattern are checked to be such rounding cases.
+# --------------------------------------------------------------------------------------------------
+def _forced_mask_parity(dev, seed, o, d, near, far, N, NF, ndc=None, white=True):
+    import copy
+    from nerf_amd import ops
+    from nerf_amd.models.NeRF import NeRF
+    from nerf_amd.render import nerf_loss, render_rays
+    torch.manual_seed(seed)
+    ref_c, ref_f = O.NeRFOracle(), O.NeRFOracle()
+    coarse, fine = NeRF(), NeRF()
+    coarse.load_state_dict(ref_c.state_dict())
+    fine.load_state_dict(ref_f.state_dict())
+    coarse, fine = coarse.to(dev), fine.to(dev)
+    R = o.shape[0]
+    g = torch.Generator().manual_seed(seed + 1)
+    u, uf, gt = torch.rand(R, N, generator=g), torch.rand(R, NF, generator=g), torch.rand(R, 3, generator=g)
+    out = render_rays(coarse, o.to(dev), d.to(dev), near, far, N, t_rand=u.to(dev), white_bkgd=white, fine_model=fine,
+                      n_importance=NF, u_fine=uf.to(dev), ndc=ndc)
+    nerf_loss(out, gt.to(dev)).backward()
+    # the ReLU patterns of the two forward passes, from a second forward over the same points (deterministic)
+    od, dd = o.to(dev), d.to(dev)
+    vd = dd / dd.norm(dim=-1, keepdim=True)
+    if ndc is not None:
+        od, dd = ops.ndc_rays(ndc[0], ndc[1], ndc[2], ndc[3], od, dd)
+    masks = []
+    for model, zz in ((coarse, out["z_vals"]), (fine, out["z_fine"])):
+        pts = (od[:, None, :] + dd[:, None, :] * zz[..., None]).reshape(-1, 3)   # what the samplers write
+        packed = ops.vanilla_pack(model._params(), False)
+        rgb, sigma, ws = ops.vanilla_fwd_raw(pts.contiguous(), vd.contiguous(), zz.shape[1], packed, True)
+        masks.append(ops.vanilla_relu_masks(ws, pts.shape[0]).cpu())
+    c_map, w, z, (f_map, w_f, z_all) = O.render_rays(ref_c, o, d, near, far, N, t_rand=u, white_bkgd=white, fine_model=ref_f,
+                                                      u_fine=uf, ndc=ndc, masks=masks[0], masks_fine=masks[1],
+                                                      z_fixed=out["z_fine"].cpu(), chunk=1 << 16)
+    (torch.nn.functional.mse_loss(c_map, gt) + torch.nn.functional.mse_loss(f_map, gt)).backward()
+    assert torch.equal(out["z_vals"].cpu(), z)
+    assert float((out["rgb"].detach().cpu() - c_map.detach()).abs().max()) < 1e-4
+    assert float((out["rgb_fine"].detach().cpu() - f_map.detach()).abs().max()) < 1e-4
+    worst = 0.0
+    for (k, p), q in zip(list(coarse.named_parameters()) + list(fine.named_parameters()),
+                         list(ref_c.parameters()) + list(ref_f.parameters())):
+        e = rel_err(p.grad.cpu(), q.grad)
+        assert e < 1e-3, (seed, k, e)                       # the contract; observed ~1e-5
+        worst = max(worst, e)
+    # disagreements between the GPU's pattern and a float64 evaluation's: few, and all of them rounding cases
+    flips = total = 0
+    for model, zz, m in ((ref_c, out["z_vals"].cpu(), masks[0]), (ref_f, out["z_fine"].cpu(), masks[1])):
+        m64 = copy.deepcopy(model).double()
+        oo, d2 = (o, d) if ndc is None else O.ndc_rays(ndc[0], ndc[1], ndc[2], ndc[3], o, d)
+        pts = (oo[:, None, :] + d2[:, None, :] * zz[..., None]).reshape(-1, 3).double()
+        dirs = (d / d.norm(dim=-1, keepdim=True))[:, None, :].expand(R, zz.shape[1], 3).reshape(-1, 3).double()
+        rec = []
+        with torch.no_grad():
+            m64(pts, dirs, masks=m.double(), record=rec)    # pre-activations along the GPU's own branch
+        pre = torch.cat(rec, dim=1)
+        differ = (pre > 0) != m.bool()
+        flips += int(differ.sum())
+        total += differ.numel()
+        if differ.any():
+            assert float(pre[differ].abs().max()) < 2e-5, "a ReLU decision differs away from zero"
+    assert flips <= 1e-4 * total
+    return worst, flips, total
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_render_gradients_meet_1e3_on_the_forward_branch(dev, seed):
+    o, d = _rays()
+    worst, flips, total = _forced_mask_parity(dev, seed, o, d, 2.0, 6.0, 64, 128)
+    print(f"seed {seed}: worst relative gradient error {worst:.2e}; {flips} of {total} ReLU decisions differ from float64")
+
+
+# --------------------------------------------------------------------------------------------------
+# Forward-facing scenes in normalised device coordinates (not in the reference: parity unpinned, pinned
+# to the oracle's definition): rays -> NDC -> depths in [0,1] -> hierarchical -> composite.
+# --------------------------------------------------------------------------------------------------
+def _forward_facing_pose():
+    """A camera near the origin looking along -z with a small tilt (what an LLFF capture looks like
+    after its poses are recentred)."""
+    rot = torch.linalg.matrix_exp(torch.tensor([[0.0, -0.03, 0.05], [0.03, 0.0, -0.02], [-0.05, 0.02, 0.0]]))
+    return torch.cat([rot, torch.tensor([[0.12], [-0.07], [0.05]])], dim=1)
+
+
+@pytest.mark.parametrize("which", ["golden_llff_pose", "forward_facing"])
+def test_ndc_hierarchical_render_step_matches_oracle(dev, which):
+    g1 = load_golden("g1_raygen.npz")
+    H, W = [int(v) // 3 for v in g1["llff_hw"]]              # 21 x 28 rays
+    f = float(g1["llff_f"][0]) / 3
+    c2w = T(g1["llff_c2w"]) if which == "golden_llff_pose" else _forward_facing_pose()
+    o, d = O.get_rays(c2w, (f, f), H, W)
+    o, d = o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()
+    worst, flips, total = _forced_mask_parity(dev, 4, o, d, 0.0, 1.0, 64, 128, ndc=(H, W, f, 1.0), white=False)
+    print(f"ndc {which}: worst relative gradient error {worst:.2e}; {flips} ReLU decisions of {total} differ")
+
+
+def test_ndc_full_image_step_504x378(dev):
+    """The whole forward-facing configuration (504 x 378 rays, 64 + 128 samples, coarse and fine 8x256 MLPs)
+    as ONE chunked training step, and the properties that hold at any size: depths inside [0,1] and sorted,
+    weights a sub-probability, expected depth inside [0,1], finite gradients on every parameter."""
+    from nerf_amd.models.NeRF import NeRF
+    from nerf_amd.render import render_rays, train_step
+    from nerf_amd.Camera import Camera
+    H, W, f = 378, 504, 3321.11 / 8
+    cam = Camera(None, None, (f, f), H, W, c2w=_forward_facing_pose().to(dev))
+    o, d = cam.get_rays()
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    torch.manual_seed(5)
+    coarse, fine = NeRF().to(dev), NeRF().to(dev)
+    R = H * W
+    gt = torch.rand(R, 3, device=dev)
+    kw = dict(fine_model=fine, n_importance=128, ndc=(H, W, f, 1.0))
+    for p in list(coarse.parameters()) + list(fine.parameters()):
+        p.grad = None
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    loss = train_step(coarse, o, d, gt, 0.0, 1.0, 64, **kw)
+    assert torch.isfinite(loss)
+    assert torch.cuda.max_memory_allocated(dev) - base < 40 << 30       # 190,512 rays unchunked would need 860 GB
+    for p in list(coarse.parameters()) + list(fine.parameters()):
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0
+    with torch.no_grad():
+        sel = torch.arange(0, R, 7, device=dev)
+        out = render_rays(coarse, o[sel], d[sel], 0.0, 1.0, 64, **kw)
+    for zk, wk, dk in (("z_vals", "weights", "depth"), ("z_fine", "weights_fine", "depth_fine")):
+        z, w, dep = out[zk], out[wk], out[dk]
+        assert float(z.min()) >= 0.0 and float(z.max()) <= 1.0
+        assert bool((z[:, 1:] >= z[:, :-1]).all())
+        assert float(w.min()) >= 0.0 and float(w.sum(dim=-1).max()) <= 1.0 + 1e-5
+        assert float(dep.min()) >= 0.0 and float(dep.max()) <= 1.0 + 1e-5
+    assert out["z_fine"].shape[1] == 192
+
+
+# --------------------------------------------------------------------------------------------------
+# Ray-chunked training step: bounded activation memory, same gradients.
+# --------------------------------------------------------------------------------------------------
+def _lego_batch(dev, R, seed=0):
+    from nerf_amd.Camera import Camera, look_at_camera
+    eye = torch.tensor([3.2, 1.8, 1.7])
+    c2w = look_at_camera(eye, 2 * eye, torch.tensor([0.0, 0.0, 1.0]))
+    g = torch.Generator().manual_seed(seed)
+    pix = torch.randperm(800 * 800, generator=g)[:R].to(torch.int32)
+    cam = Camera(None, None, (1111.11, 1111.11), 800, 800, c2w=c2w.to(dev))
+    o, d = cam.get_ray_batch(pix.to(dev))
+    return o, d, torch.rand(R, 64, generator=g).to(dev), torch.rand(R, 128, generator=g).to(dev), torch.rand(R, 3, generator=g).to(dev)
+
+
+def test_chunked_step_equals_unchunked_step(dev):
+    from nerf_amd.models.NeRF import NeRF
+    from nerf_amd.render import nerf_loss, render_rays, train_step
+    R = 8192
+    o, d, u, uf, gt = _lego_batch(dev, R)
+    torch.manual_seed(0)
+    coarse, fine = NeRF().to(dev), NeRF().to(dev)
+    params = list(coarse.parameters()) + list(fine.parameters())
+    out = render_rays(coarse, o, d, 2.0, 6.0, 64, t_rand=u, white_bkgd=True, fine_model=fine, n_importance=128, u_fine=uf)
+    loss_ref = nerf_loss(out, gt)
+    loss_ref.backward()
+    want = [p.grad.clone() for p in params]
+    del out
+    for chunk in (1024, 3000):                              # 8 equal chunks; 3 chunks with a ragged tail
+        for p in params:
+            p.grad = None
+        loss = train_step(coarse, o, d, gt, 2.0, 6.0, 64, chunk_rays=chunk, t_rand=u, u_fine=uf, white_bkgd=True,
+                          fine_model=fine, n_importance=128)
+        assert abs(float(loss) - float(loss_ref)) < 1e-6
+        for (k, p), g0 in zip(list(coarse.named_parameters()) + list(fine.named_parameters()), want):
+            # Same terms, another summation order: 1e-5.  A chunk size that is no power of two also scales the
+            # loss by a factor that is none, so every term moves by an ulp; the density head's gradient is a sum
+            # of large terms that cancel to 1e-3..1e-4 of their size (a uniform shift of log-density barely
+            # changes a render), and such a sum follows its terms only to ~1e-4 (measured 2e-4..4e-4, the same
+            # from run to run).
+            tol = 2e-3 if k.startswith("sigma_out") and chunk & (chunk - 1) else 1e-5
+            assert rel_err(p.grad, g0) < tol, (chunk, k)
+
+
+def test_65536_ray_step_fits_in_bounded_memory(dev):
+    """The data-parallel configuration's per-GPU batch: 65,536 rays x (64 + 192) evaluations of an 8x256 MLP keep
+    20 KB each for backward, 300 GB if the step ran as one piece."""
+    from nerf_amd.dist import GradBuckets
+    from nerf_amd.models.NeRF import NeRF
+    from nerf_amd.render import train_step
+    R = 65536
+    o, d, u, uf, gt = _lego_batch(dev, R, seed=1)
+    torch.manual_seed(0)
+    coarse, fine = NeRF().to(dev), NeRF().to(dev)
+    buckets = GradBuckets([list(fine.parameters()), list(coarse.parameters())])
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    loss = train_step(coarse, o, d, gt, 2.0, 6.0, 64, t_rand=u, u_fine=uf, white_bkgd=True, fine_model=fine,
+                      n_importance=128, buckets=buckets)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated(dev) - base
+    assert torch.isfinite(loss) and 0.0 < float(loss) < 2.0
+    assert peak < 40 << 30, peak                            # default workspace budget: 32 GiB + outputs
+    for p in buckets.parameters():
+        assert bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().sum()) > 0
+    assert coarse.layers_xyz[0].weight.grad.data_ptr() == buckets.views[1][0].data_ptr()
+
+
+def test_inference_under_no_grad_keeps_no_workspace(dev):
+    """Parameters that require grad do not make a no_grad forward save activations (10 KB per point)."""
+    from nerf_amd.models.FastNGPNeRF import FastNGPNeRF
+    from nerf_amd.models.NeRF import NeRF
+    torch.manual_seed(0)
+    P = 1 << 20
+    x = torch.rand(P, 3, device=dev)
+    dirs = torch.nn.functional.normalize(torch.randn(P, 3, device=dev), dim=-1)
+    for model in (NeRF().to(dev), FastNGPNeRF(log2_hashmap_size=14).to(dev)):
+        assert all(p.requires_grad for p in model.parameters())
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        with torch.no_grad():
+            rgb, sigma = model(x, dirs)
+        torch.cuda.synchronize()
+        assert torch.cuda.max_memory_allocated(dev) - base < 64 << 20, type(model).__name__   # outputs 16 MB + packed weights
+        assert not rgb.requires_grad
+        rgb2, _ = model(x[:4096], dirs[:4096])
+        assert rgb2.requires_grad and torch.equal(rgb2.detach(), rgb[:4096])
+
+
+def test_ngp_training_render_with_occupancy_grid(dev):
+    """sigma zeroed outside the occupancy grid before compositing, masked samples without gradient
+    (src/train_nerf_ngp.py:113-117), against the oracle composed the same way."""
+    from nerf_amd.models.FastNGPNeRF import FastNGPNeRF
+    from nerf_amd.render import get_density_grid, render_rays
+    torch.manual_seed(2)
+    ref = O.FastNGPNeRFOracle(log2_hashmap_size=14)
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if k != "fc_density.2.bias":                     # tables too: the density must vary over space
+                p.copy_(torch.randn_like(p) * (0.5 if p.dim() > 1 else 0.1))
+        ref.fc_density[2].bias[0] = -1.0                     # densities on both sides of the threshold of 1
+    m = FastNGPNeRF(log2_hashmap_size=14)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(dev)
+    grid_res = 32
+    grid = get_density_grid(m, dev, grid_res)
+    grid_ref = O.get_density_grid(ref, grid_res)
+    occupied = float(grid_ref.float().mean())
+    assert 0.05 < occupied < 0.95, occupied                  # a grid that masks something and keeps something
+    # cells whose density is within rounding of the threshold may differ; use one grid on both sides
+    assert float((grid.cpu() != grid_ref).float().mean()) < 1e-3
+    o, d = _rays()
+    o = o * 0.1
+    R, N = o.shape[0], 64
+    g = torch.Generator().manual_seed(3)
+    u, gt = torch.rand(R, N, generator=g), torch.rand(R, 3, generator=g)
+    out = render_rays(m, o.to(dev), d.to(dev), 0.05, 1.2, N, t_rand=u.to(dev), density_grid=grid_ref.to(dev), grid_res=grid_res)
+    loss = torch.nn.functional.mse_loss(out["rgb"], gt.to(dev)) + 0.05 * (1 - out["weights"].sum(dim=-1)).abs().mean()
+    loss.backward()
+    c_map, w, z, _ = O.render_rays(ref, o, d, 0.05, 1.2, N, t_rand=u, chunk=16384, density_grid=grid_ref, grid_res=grid_res)
+    loss_o = torch.nn.functional.mse_loss(c_map, gt) + 0.05 * (1 - w.sum(dim=-1)).abs().mean()
+    loss_o.backward()
+    masked = float((w == 0).float().mean())
+    assert 0.02 < masked < 0.98, masked
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 1e-5
+    assert float((out["rgb"].detach().cpu() - c_map.detach()).abs().max()) < 1e-4
+    assert float((out["weights"].detach().cpu() - w.detach()).abs().max()) < 1e-5
+    for (k, p), q in zip(m.named_parameters(), ref.parameters()):
+        err = float((p.grad.cpu() - q.grad).norm())
+        assert err <= 1e-3 * float(q.grad.norm()) + 1e-9, (k, err, float(q.grad.norm()))

@@ -197,3 +197,56 @@ def test_ndc_rays_maps_near_plane_to_minus_one():
     o2, d2 = O.ndc_rays(378, 504, 415.0, 1.0, o, d)
     assert torch.allclose(o2[:, 2], torch.tensor([-1.0, -1.0]), atol=1e-6)
     assert torch.allclose((o2 + d2)[:, 2], torch.tensor([1.0, 1.0]), atol=1e-6)  # t=1 is infinity
+
+
+def test_legacy_free_functions_match_reference():
+    """The older helpers of src/utils/get_rays.py: +z camera, [W,H,3] rays, 1e10 tail."""
+    g = load_golden("g8_legacy.npz")
+    eye, tgt = T(g["eye"]), T(g["tgt"])
+    up = O.legacy_compute_stable_up(eye, tgt)
+    assert torch.equal(up, T(g["up"]))
+    assert torch.equal(O.legacy_compute_stable_up(torch.tensor([0.0, -3.0, 0.0]), torch.zeros(3)), T(g["up_vert"]))
+    c2w = O.legacy_look_at_camera(eye, tgt, up)
+    assert torch.equal(c2w, T(g["c2w"]))
+    H, W, focal = int(g["hwf"][0]), int(g["hwf"][1]), float(g["hwf"][2])
+    o, d = O.legacy_get_rays(H, W, focal, c2w)
+    assert o.shape == (W, H, 3) and torch.equal(o, T(g["rays_o"])) and torch.equal(d, T(g["rays_d"]))
+    near, far, n = float(g["cfg"][0]), float(g["cfg"][1]), int(g["cfg"][2])
+    pts, z = O.sample_points_along_rays(o, d, near, far, n, None)
+    assert torch.equal(pts, T(g["pts"])) and torch.equal(z.contiguous(), T(g["z"]))
+    for name, fn in (("complex", O.analytic_field), ("sphere", O.analytic_field_sphere), ("torus", O.analytic_field_torus)):
+        rgb, sigma = fn(pts)
+        assert torch.equal(rgb.contiguous(), T(g[name + "_rgb"])) and torch.equal(sigma, T(g[name + "_sigma"])), name
+        assert torch.equal(O.legacy_volume_render(rgb, sigma, z), T(g[name + "_img"])), name
+    g6 = load_golden("g6_composite.npz")
+    assert torch.equal(O.legacy_volume_render(T(g6["a_rgb"]), T(g6["a_sigma"]), T(g6["a_z"])), T(g6["legacy_c"]))
+
+
+def test_forced_relu_masks_reproduce_the_network():
+    """Forcing the ReLU pattern the network takes by itself changes nothing; the recorded pre-activations
+    are what the pattern is derived from."""
+    torch.manual_seed(3)
+    m = O.NeRFOracle()
+    x, d = torch.randn(40, 3), torch.nn.functional.normalize(torch.randn(40, 3), dim=-1)
+    rec = []
+    rgb, sigma = m(x, d, record=rec)
+    assert [r.shape[1] for r in rec] == [256] * 8 + [128]
+    masks = torch.cat([r > 0 for r in rec], dim=1)
+    rgb_m, sigma_m = m(x, d, masks=masks)
+    assert torch.equal(rgb, rgb_m) and torch.equal(sigma, sigma_m)
+    a, b = m(x, d)
+    assert torch.equal(rgb, a) and torch.equal(sigma, b)
+
+
+def test_occupancy_mask_semantics():
+    """sigma is zeroed where the grid cell is empty, cells are indexed with res = 32 whatever grid_res is."""
+    grid = torch.zeros(32 ** 3, dtype=torch.uint8)
+    pts = torch.tensor([[-1.0, -1.0, -1.0], [0.0, 0.0, 0.0], [0.99, 0.99, 0.99], [-0.5, 0.25, 0.75]])
+    cells = ((pts + 1) / 2 * 32).long()
+    grid[O.xyz_to_idx(cells[1, 0], cells[1, 1], cells[1, 2])] = 1
+    grid[O.xyz_to_idx(cells[3, 0], cells[3, 1], cells[3, 2])] = 1
+    sigma = torch.tensor([1.0, 2.0, 3.0, 4.0], requires_grad=True)
+    out = O.occupancy_mask(sigma, pts, grid, 32)
+    assert out.tolist() == [0.0, 2.0, 0.0, 4.0]
+    out.sum().backward()
+    assert sigma.grad.tolist() == [0.0, 1.0, 0.0, 1.0]
