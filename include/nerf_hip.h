@@ -236,6 +236,18 @@ size_t nerf_clip_grad_norm_workspace_floats(int count, const int64_t* numel);
 int nerf_clip_grad_norm(int count, float* const* grads, const int64_t* numel, float max_norm,
                         float* workspace, float* total_norm, void* stream);
 
+/* nerf_clip_grad_norm without the workspace argument.  No counterpart in the reference: it is for
+ * callers that cannot allocate device memory (code under HIP graph capture, tight serving or
+ * training loops, harnesses that forbid allocation).  The scratch is a 256 KiB array built into the
+ * library's device image (each GPU the library runs on holds its own copy until the process ends);
+ * the call allocates and frees nothing.  Limit: the gradients together may span at most 65,536 chunks
+ * of 4,096 elements (each tensor rounds up to whole chunks; 268,435,456 elements at most) -- more is
+ * rejected with NERF_EINVAL.  Every call on a GPU uses that GPU's one array: calls that overlap on
+ * the same GPU (two streams, two threads) race; calls on one stream, or on different GPUs, do not.
+ * Same results as nerf_clip_grad_norm, bit for bit. */
+int nerf_clip_grad_norm_static(int count, float* const* grads, const int64_t* numel, float max_norm,
+                               float* total_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

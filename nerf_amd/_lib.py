@@ -50,6 +50,7 @@ SIGNATURES = {
     "nerf_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
     "nerf_clip_grad_norm_workspace_floats": (C.c_size_t, [_I, _P]),
     "nerf_clip_grad_norm": (_I, [_I, _P, _P, _F, _P, _P, _P]),
+    "nerf_clip_grad_norm_static": (_I, [_I, _P, _P, _F, _P, _P]),
 }
 
 _lib = None

@@ -7,6 +7,8 @@
 // hash-grid model (10.4 M parameters) are 290 MB of traffic per step.
 // Compiled with -ffp-contract=off so that every product and sum rounds like the separate
 // ops of torch's single-tensor implementation.
+#include <atomic>
+
 #include "common.h"
 
 namespace nerf {
@@ -217,6 +219,34 @@ static int clip_run(int count, float* const* grads, const int64_t* numel, long l
     return clip_pass<true>(count, grads, numel, scratch, stream);
 }
 
+// ---------------------------------------------------------------------------
+// The same clipping for callers that cannot allocate (code under HIP graph capture, serving or
+// training loops with a fixed memory plan): the scratch floats live in this file-scope device
+// array instead of a caller workspace.  Each GPU holds its own copy of the array at its own
+// address, looked up once per device; `scratch` itself is only a host-side handle and is never
+// passed to a kernel or a memset.
+// ---------------------------------------------------------------------------
+constexpr long long CLIP_STATIC_MAX_CHUNKS = 65536;   // 268,435,456 gradient elements (1 GiB of float32)
+static __device__ __align__(256) float scratch[2 + CLIP_STATIC_MAX_CHUNKS + 62];   // 256.25 KiB per GPU
+constexpr int CLIP_MAX_DEVICES = 64;
+static std::atomic<float*> scratch_ptr[CLIP_MAX_DEVICES];
+
+// Device address of the current device's copy of `scratch` (looked up on the first call on that device).
+static int clip_static_scratch(float** out) {
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= CLIP_MAX_DEVICES)
+        return fail(NERF_ELAUNCH, "nerf_clip_grad_norm_static: no current device (or device index above %d)", CLIP_MAX_DEVICES - 1);
+    float* p = scratch_ptr[device].load(std::memory_order_acquire);
+    if (!p) {
+        const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(NERF_ELAUNCH, "nerf_clip_grad_norm_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+        scratch_ptr[device].store(p, std::memory_order_release);   // two threads racing here store the same address
+    }
+    *out = p;
+    return NERF_OK;
+}
+
 }  // namespace nerf
 
 using namespace nerf;
@@ -265,4 +295,19 @@ extern "C" int nerf_clip_grad_norm(int count, float* const* grads, const int64_t
     const long long chunks = clip_chunks(count, grads, numel);
     NERF_REQUIRE(chunks >= 0 && chunks < (1ll << 31), "nerf_clip_grad_norm: bad tensor list");
     return clip_run(count, grads, numel, chunks, max_norm, workspace, total_norm, (hipStream_t)stream);
+}
+
+extern "C" int nerf_clip_grad_norm_static(int count, float* const* grads, const int64_t* numel, float max_norm,
+                                          float* total_norm, void* stream) {
+    NERF_REQUIRE(count >= 0 && (count == 0 || (grads && numel)), "nerf_clip_grad_norm_static: null pointer");
+    const long long chunks = clip_chunks(count, grads, numel);
+    NERF_REQUIRE(chunks >= 0, "nerf_clip_grad_norm_static: bad tensor list");
+    NERF_REQUIRE(chunks <= CLIP_STATIC_MAX_CHUNKS,
+                 "nerf_clip_grad_norm_static: %lld chunks of %d elements exceed the built-in scratch of %lld chunks "
+                 "(%lld elements in all); use nerf_clip_grad_norm with a workspace",
+                 chunks, CLIP_CHUNK, CLIP_STATIC_MAX_CHUNKS, CLIP_STATIC_MAX_CHUNKS * CLIP_CHUNK);
+    float* ptr = nullptr;
+    if (int rc = clip_static_scratch(&ptr)) return rc;
+    // nothing in the scratch has to start at zero: every partial that is read is written first by this call
+    return clip_run(count, grads, numel, chunks, max_norm, ptr, total_norm, (hipStream_t)stream);
 }
