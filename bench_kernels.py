@@ -74,12 +74,12 @@ def main():
         dep = torch.empty(R, device=dev)
         lib = L.lib()
         st = L.stream_of(rgb)
-        a_cf = (L.ptr(rgb), L.ptr(sigma), L.ptr(zz), R, n, 1, L.ptr(out), L.ptr(w), L.ptr(dep), st)
+        a_cf = (L.ptr(rgb), L.ptr(sigma), L.ptr(zz), R, n, 1, 1e5, L.ptr(out), L.ptr(w), L.ptr(dep), st)
         t = timeit(lambda: lib.nerf_composite_fwd(*a_cf))
         report("composite_fwd (%d samples)" % n, R * n * 24 + R * 16, t, "read rgb,sigma,z; write weights,colour,depth")
         d_out = torch.randn(R, 3, generator=g).to(dev)
         d_rgb, d_sig = torch.empty_like(rgb), torch.empty_like(sigma)
-        a_cb = (L.ptr(rgb), L.ptr(sigma), L.ptr(zz), L.ptr(d_out), None, None, R, n, 1, L.ptr(d_rgb), L.ptr(d_sig), st)
+        a_cb = (L.ptr(rgb), L.ptr(sigma), L.ptr(zz), L.ptr(d_out), None, None, R, n, 1, 1e5, L.ptr(d_rgb), L.ptr(d_sig), st)
         t = timeit(lambda: lib.nerf_composite_bwd(*a_cb))
         report("composite_bwd (%d samples)" % n, R * n * 36 + R * 12, t, "read rgb,sigma,z,d_out; write d_rgb,d_sigma")
         if n == N:
@@ -107,8 +107,13 @@ def main():
     sizes = [int(tb.shape[0]) for tb in tabs]
     lib = L.lib()
     t = timeit(lambda: L.check(lib.nerf_hashgrid_bwd(L.ptr(xs), P, L.ptr(d_out), L.int_array(res), L.int_array(sizes), 16,
-                                                     L.ptr_array(grads), L.stream_of(xs)), "hbwd"), iters=5)
-    report("hashgrid_bwd (16 levels)", P * (16 * 8 * 8 + 12 + 128), t, "1,024 B/point of float atomics")
+                                                     L.ptr_array(grads), None, 0, L.stream_of(xs)), "hbwd"), iters=5)
+    report("hashgrid_bwd (16 levels, direct atomics)", P * (16 * 8 * 8 + 12 + 128), t, "1,024 B/point of float atomics")
+    work, nbytes = ops.scatter_workspace(P, sizes, dev)
+    t = timeit(lambda: L.check(lib.nerf_hashgrid_bwd(L.ptr(xs), P, L.ptr(d_out), L.int_array(res), L.int_array(sizes), 16,
+                                                     L.ptr_array(grads), L.ptr(work), nbytes, L.stream_of(xs)), "hbwd"), iters=5)
+    report("hashgrid_bwd (16 levels, binned by table segment)", P * (16 * 8 * 8 + 12 + 128), t,
+           "updates sorted by segment through a %d MB workspace, summed in LDS" % (nbytes >> 20))
 
     dirs = torch.randn(R, 3, generator=g).to(dev)
     with torch.no_grad():

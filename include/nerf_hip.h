@@ -104,9 +104,16 @@ int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* tables, con
 
 /* Backward of the above w.r.t. the tables (the reference gets it from the
  * dense nn.Embedding gradient).  d_out [P, 2*levels]; d_tables: host array of
- * device pointers, ACCUMULATED into with float atomics (zero them first). */
+ * device pointers, ACCUMULATED into with float atomics (zero them first).
+ * workspace: device scratch of nerf_hashgrid_bwd_workspace_bytes(P, sizes, levels) bytes, with which
+ * the updates of the tables too large for LDS are first sorted by table segment and summed in LDS
+ * (several times faster at thousands of rays); NULL (or a size of 0, which that function returns
+ * for small P) makes every update a float atomic on the table.  Same sums either way, up to the
+ * order of the additions. */
+size_t nerf_hashgrid_bwd_workspace_bytes(int64_t P, const int* sizes, int levels);
 int nerf_hashgrid_bwd(const float* x, int64_t P, const float* d_out, const int* res,
-                      const int* sizes, int levels, float* const* d_tables, void* stream);
+                      const int* sizes, int levels, float* const* d_tables, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ----------------------------------------------------------- composite ---- */
 
@@ -210,11 +217,12 @@ int nerf_mlp_ngp_fwd(const float* x, const float* dirs, int dirs_div, int64_t P,
                      const float* packed, float* rgb, float* sigma, float* ws, void* stream);
 /* Gradients of the 9 MLP parameters (`grads`, same order/shapes) and of the 16
  * tables (`d_tables`), all ACCUMULATED with float atomics: zero them first.
- * ws2: ceil32(P)*ws2_floats_per_point floats of scratch. */
+ * ws2: ceil32(P)*ws2_floats_per_point floats of scratch.  scatter_ws / scatter_ws_bytes: the
+ * workspace of nerf_hashgrid_bwd (nerf_hashgrid_bwd_workspace_bytes(P, sizes, 16)), or NULL / 0. */
 int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, int64_t P,
                      const int* res, const int* sizes, const float* packed, const float* rgb,
                      const float* sigma, float* ws, float* ws2, float* const* d_tables,
-                     float* const* grads, void* stream);
+                     float* const* grads, void* scatter_ws, size_t scatter_ws_bytes, void* stream);
 
 /* One Adam step over `count` tensors in one launch: torch.optim.Adam (no amsgrad), the optimiser
  * of the reference's training loops (src/train_nerf_llff.py:82 and src/train_nerf_skow.py:47: lr 5e-4,

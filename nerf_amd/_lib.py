@@ -30,7 +30,8 @@ SIGNATURES = {
     "nerf_ndc_rays": (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P, _P]),
     "nerf_encode_pe": (_I, [_P, _L, _I, _I, _P, _P]),
     "nerf_hashgrid_fwd": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "nerf_hashgrid_bwd": (_I, [_P, _L, _P, _P, _P, _I, _P, _P]),
+    "nerf_hashgrid_bwd_workspace_bytes": (C.c_size_t, [_L, _P, _I]),
+    "nerf_hashgrid_bwd": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, C.c_size_t, _P]),
     "nerf_composite_fwd": (_I, [_P, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P]),
     "nerf_composite_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _P]),
     "nerf_occupancy_mask": (_I, [_P, _P, _L, _P, _L, _I, _P, _P]),
@@ -46,7 +47,7 @@ SIGNATURES = {
     "nerf_mlp_ngp_ws2_floats_per_point": (C.c_size_t, []),
     "nerf_mlp_ngp_pack": (_I, [_P, _P, _P]),
     "nerf_mlp_ngp_fwd": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "nerf_mlp_ngp_bwd": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_mlp_ngp_bwd": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "nerf_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
     "nerf_clip_grad_norm_workspace_floats": (C.c_size_t, [_I, _P]),
     "nerf_clip_grad_norm": (_I, [_I, _P, _P, _F, _P, _P, _P]),

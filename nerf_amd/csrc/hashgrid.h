@@ -100,8 +100,11 @@ __device__ __forceinline__ float corner_weight(const Cell& c, int corner) {
 }
 
 // d_tables[l][row][f] += corner weight * d_enc[p][2l + f] over all points and corners
-// (the backward of the hash-grid gather); defined with the encoder kernels.
+// (the backward of the hash-grid gather); defined with the encoder kernels.  With a workspace of
+// hashgrid_scatter_workspace_bytes() the updates of the large tables are binned by table segment and summed
+// in LDS; without one (or when that size is 0: few points) every update is a float atomic on the table.
+size_t hashgrid_scatter_workspace_bytes(int64_t P, const int* sizes, int levels);
 int launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, const int* res, const int* sizes, int levels,
-                            float* const* d_tables, hipStream_t stream);
+                            float* const* d_tables, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace nerf

@@ -20,35 +20,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __host__ __device__ __forceinline__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// A 32-point x 256-wide tile staged in a wave-private LDS buffer (rows of 260
-// floats) that still has to be written to a row-major [P32][256] array.  The rows
-// are trickled out between the MFMA groups of the NEXT layer (one row every few
-// k-steps): every wave of the chip reaches its layer boundary at about the same
-// time, so storing the tile there is a 32 MB burst that stalls all of them on the
-// memory pipeline, while spread over the following 65k cycles it is free.
-constexpr int STAGE_LD = 256 + 4;
-struct PendingRows {
-    const float* lds;   // this wave's staging buffer
-    float* rows0;       // row 0 of the tile in global memory (leading dimension 256)
-};
-
-// acc[ot] += W_tile(ot, kt) * in[kt] for all tiles.  wp: packed [KT][16][64][OT].
-// DRAIN: also write the 32 pending rows of `pend` to global memory along the way.
-template <int KT, int OT, bool DRAIN = false>
+// acc[ot] += W_tile(ot, kt) * in[kt] for all tiles on the exact-f32 MFMA, weights straight from memory
+// (the small layers of the hash-grid model).  wp: packed [KT][16][64][OT].
+template <int KT, int OT>
 __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16 (&in)[KT], f32x16 (&acc)[OT],
-                                      int lane, PendingRows pend = PendingRows{nullptr, nullptr}) {
+                                      int lane) {
     static_assert(OT % 4 == 0 || OT == 1 || OT == 2, "OT must be 1, 2 or a multiple of 4");
     typedef float wvec __attribute__((ext_vector_type(OT >= 4 ? 4 : OT)));  // one load: 16, 8 or 4 bytes per lane
     constexpr int W = OT >= 4 ? 4 : OT;
     constexpr int V = OT / W;
     constexpr int S = KT * 16;       // k-steps; one step = OT MFMAs sharing one B register
-#ifndef NERF_RING_DEPTH
-#define NERF_RING_DEPTH 4
-#endif
-    constexpr int D = S < NERF_RING_DEPTH ? S : NERF_RING_DEPTH;  // steps of weight prefetch kept in flight (L2 latency >> one step)
+    constexpr int D = S < 4 ? S : 4;  // steps of weight prefetch kept in flight (L2 latency >> one step)
     const wvec* __restrict__ w4 = reinterpret_cast<const wvec*>(wp) + lane * V;
     wvec ring[D][V];
-    float4 drain_buf = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < D; ++s)
 #pragma unroll
@@ -65,15 +49,6 @@ __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16
         if (s + D < S) {
 #pragma unroll
             for (int v = 0; v < V; ++v) ring[s % D][v] = w4[(size_t)((s + D) * 64) * V + v];
-        }
-        if constexpr (DRAIN) {
-            // row j is read from LDS at step PER*j and stored half a period later
-            constexpr int PER = S >= 64 ? S / 32 : 1;
-            static_assert(S >= 33, "too few k-steps to drain 32 rows");
-            if (s % PER == 0 && s / PER < 32)
-                drain_buf = *reinterpret_cast<const float4*>(pend.lds + (s / PER) * STAGE_LD + 4 * lane);
-            if (s >= (PER + 1) / 2 && (s - (PER + 1) / 2) % PER == 0 && (s - (PER + 1) / 2) / PER < 32)
-                *reinterpret_cast<float4*>(pend.rows0 + (size_t)((s - (PER + 1) / 2) / PER) * 256 + 4 * lane) = drain_buf;
         }
         // Pin the order "issue the prefetch, then this step's MFMAs": left alone the
         // scheduler sinks every load to just before its use and exposes its latency.
@@ -124,12 +99,8 @@ __device__ __forceinline__ void vm_wait() {
 }
 __device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-constexpr int WS_CHUNK_STEPS = 16;
-constexpr int WS_CHUNK_FLOATS = WS_CHUNK_STEPS * 8 * 64;   // largest chunk: 16 k-steps of 8 output tiles (32 KiB)
-constexpr int WS_LDS_FLOATS = 3 * WS_CHUNK_FLOATS;
 constexpr int TILE_LD = 36;                                // row pitch of the 32 x 32 transposition buffer
 constexpr int TILE_LDS_FLOATS = 32 * TILE_LD;
-constexpr int MLP_LDS_FLOATS = WS_LDS_FLOATS + 4 * TILE_LDS_FLOATS;   // per workgroup of 4 waves
 
 __device__ __forceinline__ int wrap3(int x) { return x >= 3 ? x - 3 : x; }
 
@@ -137,22 +108,9 @@ struct WeightStream {
     float* lds;   // the chunk buffers shared by the workgroup
     int g3;       // buffer of the chunk the next dense layer starts with
     int wave, lane;
-    const float* next = nullptr;   // bf16 x 6 stream: the next chunk to copy, and where the packed layers end
+    const float* next = nullptr;   // the next chunk to copy, and where the packed layers end
     const float* end = nullptr;
 };
-// The two chunks that follow a layer's own in the stream, as 1 KiB pieces per wave (0 = none).
-struct NextChunks {
-    const float* p0; int pw0;
-    const float* p1; int pw1;
-};
-// The chunks after a layer of N_FLOATS packed floats whose successor has OT_NEXT output tiles
-// (and at least two chunks; the packed layers of a kernel are contiguous in stream order).
-template <int OT_NEXT>
-__device__ __forceinline__ NextChunks next_chunks(const float* after) {
-    constexpr int CHF = WS_CHUNK_STEPS * OT_NEXT * 64;
-    return NextChunks{after, CHF / 1024, after + CHF, CHF / 1024};
-}
-
 // A wave's 32 x 36 float transposition buffer, for writing register tiles (32 points x
 // 32 neurons) to a row-major array as whole 128-byte row segments: ds_write_b128 in the
 // register layout, ds_read_b128 + one 16-byte store per lane in the row layout (lane L:
@@ -166,7 +124,7 @@ __device__ __forceinline__ TileBuf tile_buf(float* lds_wave, int lane) {
     return TileBuf{lds_addr(lds_wave + (lane & 31) * TILE_LD + 4 * (lane >> 5)),
                    lds_addr(lds_wave + (lane >> 3) * TILE_LD + 4 * (lane & 7)), lane >> 3, 4 * (lane & 7)};
 }
-// Rows to write underneath a dense_shared() call: its input tiles, to rows0[32][ld].
+// Rows to write underneath a dense_x6() call: its input tiles, to rows0[32][ld].
 struct TileSave {
     TileBuf tb;
     float* rows0;   // row 0 of the tile's 32 rows, already offset by this lane's (row, col)
@@ -202,12 +160,6 @@ __device__ __forceinline__ void ws_copy_piece(const WeightStream& ws, const floa
                                      (__attribute__((address_space(3))) void*)(buf + piece * 256), 16, 0, 0);
 }
 
-// Start the stream: request its first two chunks.  ws_ready() must follow before the first dense_shared().
-__device__ __forceinline__ void ws_prime(WeightStream& ws, const float* c0, int pw0, const float* c1, int pw1) {
-    for (int q = 0; q < pw0; ++q) ws_copy_piece(ws, c0, ws.lds, q);
-    for (int q = 0; q < pw1; ++q) ws_copy_piece(ws, c1, ws.lds + WS_CHUNK_FLOATS, q);
-    ws.g3 = 0;
-}
 // YOUNGER: vector memory operations this wave has issued after its last copy (they complete in
 // issue order, so the wait may leave that many in flight; waiting for a store just issued costs
 // its whole trip to memory).
@@ -215,81 +167,6 @@ template <int YOUNGER = 0>
 __device__ __forceinline__ void ws_ready() {
     vm_wait<YOUNGER>();
     __builtin_amdgcn_s_barrier();
-}
-
-// acc[ot] += W_tile(ot, kt) * in[kt] for all tiles, weights from the stream.  wp: this layer's
-// packed weights [KT][16][64][OT]; nx: what follows them in the stream.
-// DRAIN: also write the input tiles to sv.rows0 (row-major), tile kt during chunk kt.
-template <int KT, int OT, bool DRAIN = false>
-__device__ __forceinline__ void dense_shared(WeightStream& ws, const float* __restrict__ wp, const NextChunks nx,
-                                             const f32x16 (&in)[KT], f32x16 (&acc)[OT],
-                                             TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
-    static_assert(OT % 4 == 0, "operands are read 16 bytes at a time");
-    constexpr int STEP = OT * 64, CHF = WS_CHUNK_STEPS * STEP, PW = CHF / 1024, V = OT / 4;
-    f32x4 a0[V], a1[V];
-    f32x4 dbuf = {0.f, 0.f, 0.f, 0.f};
-    static_for<0, KT>([&](auto ci) {
-        constexpr int i = decltype(ci)::value;
-        const int b0 = wrap3(ws.g3 + i % 3);
-        const unsigned rd = lds_addr(ws.lds + b0 * WS_CHUNK_FLOATS) + ws.lane * (OT * 4);
-        const unsigned rd_next = lds_addr(ws.lds + wrap3(b0 + 1) * WS_CHUNK_FLOATS) + ws.lane * (OT * 4);
-        float* buf2 = ws.lds + wrap3(b0 + 2) * WS_CHUNK_FLOATS;
-        if constexpr (i == 0) static_for<0, V>([&](auto v) { a0[v] = lds_read4<decltype(v)::value * 16>(rd); });
-        static_for<0, WS_CHUNK_STEPS>([&](auto cj) {
-            constexpr int j = decltype(cj)::value;
-            constexpr int s = WS_CHUNK_STEPS * i + j;
-            f32x4(&cur)[V] = (s % 2 == 0) ? a0 : a1;
-            f32x4(&nxt)[V] = (s % 2 == 0) ? a1 : a0;
-            // Schedule of a k-step: wait for its operands (requested a whole step ago), its
-            // first MFMA, then the requests for the next step, the copies and the row
-            // traffic, then the other MFMAs.  Operands pass through an empty asm so that no
-            // use of them moves above the wait, accumulators so that no MFMA sinks.
-            lgkm_wait();
-#pragma unroll
-            for (int v = 0; v < V; ++v) asm volatile("" : "+v"(cur[v]));
-            if constexpr (DRAIN) asm volatile("" : "+v"(dbuf));
-            const float b = in[i][j];
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][0], b, acc[0], 0, 0, 0);
-            asm volatile("" : "+a"(acc[0]));
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j == WS_CHUNK_STEPS / 2) ws_ready<DRAIN ? 2 : 0>();   // DRAIN: the row stores of steps 3 and 6
-            if constexpr (j >= WS_CHUNK_STEPS / 2) {
-                constexpr int q = j - WS_CHUNK_STEPS / 2;
-                if constexpr (i + 2 < KT) {
-                    if constexpr (q < PW) ws_copy_piece(ws, wp + (i + 2) * CHF, buf2, q);
-                } else if constexpr (i + 2 - KT == 0) {
-                    if (q < nx.pw0) ws_copy_piece(ws, nx.p0, buf2, q);
-                } else {
-                    if (q < nx.pw1) ws_copy_piece(ws, nx.p1, buf2, q);
-                }
-            }
-            if constexpr (j + 1 < WS_CHUNK_STEPS) {
-                static_for<0, V>([&](auto v) { nxt[v] = lds_read4<(j + 1) * STEP * 4 + decltype(v)::value * 16>(rd); });
-            } else if constexpr (i + 1 < KT) {
-                static_for<0, V>([&](auto v) { nxt[v] = lds_read4<decltype(v)::value * 16>(rd_next); });
-            }
-            if constexpr (DRAIN) {
-                if constexpr (j == 0) {
-                    static_for<0, 4>([&](auto cq) {
-                        constexpr int q = decltype(cq)::value;
-                        lds_write4<32 * q>(sv.tb.wr, f32x4{in[i][4 * q], in[i][4 * q + 1], in[i][4 * q + 2], in[i][4 * q + 3]});
-                    });
-                }
-                if constexpr (j >= 2 && j <= 11 && (j - 2) % 3 == 0) dbuf = lds_read4<8 * ((j - 2) / 3) * TILE_LD * 4>(sv.tb.rd);
-                if constexpr (j >= 3 && j <= 12 && (j - 3) % 3 == 0)
-                    *reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * ((j - 3) / 3)) * sv.ld + 32 * i) = dbuf;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ot = 1; ot < OT; ++ot) {
-                acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[ot / 4][ot % 4], b, acc[ot], 0, 0, 0);
-                asm volatile("" : "+a"(acc[ot]));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    });
-    ws.g3 = wrap3(ws.g3 + KT % 3);
 }
 
 // ------------------------------------------------------ bf16 x 6 dense ----
@@ -593,58 +470,6 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, const f32x16 
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(row + 32 * t + 8 * q + 4 * h) =
                 make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
-}
-
-// Coalesced form of store_row for a whole 32-point tile: the wave transposes its
-// registers through a private LDS buffer (32 rows of 32*NT + 4 floats; the pad
-// spreads the 8 rows of a ds_write_b128 group over all banks) and then writes
-// whole rows, 1 KiB contiguous per store instruction.  Stored straight from the
-// register layout a store instruction touches 32 different 128-byte lines, 32
-// bytes each, which costs the forward kernel ~14 % of its time.
-// rows0: row 0 of this tile in a row-major [P32][ld] array.
-constexpr int STORE_LDS_FLOATS_PER_WAVE = 32 * (256 + 4);
-template <int NT>
-__device__ __forceinline__ void drain_tile_rows(const float* __restrict__ lds_wave, float* __restrict__ rows0, int ld,
-                                                int lane);
-template <int NT>
-__device__ __forceinline__ void store_tile_rows(float* __restrict__ lds_wave, float* __restrict__ rows0, int ld,
-                                                const f32x16 (&a)[NT], int lane) {
-    constexpr int WIDTH = 32 * NT, LD = WIDTH + 4;
-    static_assert(256 % WIDTH == 0 && 32 * LD <= STORE_LDS_FLOATS_PER_WAVE, "tile does not fit the staging buffer");
-    const int p = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(lds_wave + p * LD + 32 * t + 8 * q + 4 * h) =
-                make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
-    drain_tile_rows<NT>(lds_wave, rows0, ld, lane);
-}
-
-// First half of store_tile_rows only: park a 256-wide tile in the staging buffer
-// (layout of PendingRows); dense<..., DRAIN> or drain_tile_rows writes it out.
-__device__ __forceinline__ void stage_tile(float* __restrict__ lds_wave, const f32x16 (&a)[8], int lane) {
-    const int p = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(lds_wave + p * STAGE_LD + 32 * t + 8 * q + 4 * h) =
-                make_float4(a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]);
-}
-
-template <int NT>
-__device__ __forceinline__ void drain_tile_rows(const float* __restrict__ lds_wave, float* __restrict__ rows0, int ld,
-                                                int lane) {
-    constexpr int WIDTH = 32 * NT, LD = WIDTH + 4;
-    constexpr int ROWS_PER_INS = 256 / WIDTH;   // rows covered by one 64-lane float4 access
-    const int sub = (lane * 4) / WIDTH, col = (lane * 4) % WIDTH;
-#pragma unroll
-    for (int r0 = 0; r0 < 32; r0 += ROWS_PER_INS) {
-        const int row = r0 + sub;
-        const float4 v = *reinterpret_cast<const float4*>(lds_wave + row * LD + col);
-        *reinterpret_cast<float4*>(rows0 + (size_t)row * ld + col) = v;
-    }
 }
 
 // One bit per neuron: 1 where the (post-ReLU) activation is > 0.  Word t>>1, bit (t&1)*16 + r.

@@ -315,7 +315,8 @@ extern "C" int nerf_mlp_ngp_fwd(const float* x, const float* dirs, int dirs_div,
 
 extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, int64_t P, const int* res,
                                 const int* sizes, const float* packed, const float* rgb, const float* sigma, float* ws,
-                                float* ws2, float* const* d_tables, float* const* grads, void* stream) {
+                                float* ws2, float* const* d_tables, float* const* grads, void* scatter_ws,
+                                size_t scatter_ws_bytes, void* stream) {
     if (P == 0) return NERF_OK;
     NERF_REQUIRE(x && d_rgb && d_sigma && res && sizes && packed && rgb && sigma && ws && ws2 && d_tables && grads,
                  "nerf_mlp_ngp_bwd: null pointer");
@@ -350,7 +351,7 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
         p.k_first = 1;
         parts.part[n++] = p;
     }
-    if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, res, sizes, 16, d_tables, st)) return rc;
+    if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st)) return rc;
     parts.n = n;
     if (int rc = launch_wgrad(parts, P32, st)) return rc;
     SkinnyPart c2{DOUT4, HC, grads[6], grads[7], 4, 64, 1, 3, 64};                                           // fc_color.2

@@ -307,13 +307,6 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
 // are prepared right after the chunk's barrier, the only part that runs without MFMAs; the
 // per-chunk state stays local to the chunk (carried across the chunk loop it costs twice
 // the registers, and a spilled operand of an asm load is spilled before it has arrived).
-#ifndef NERF_WGRAD_PK
-#define NERF_WGRAD_PK 1
-#endif
-#ifndef NERF_WGRAD_X6
-#define NERF_WGRAD_X6 1
-#endif
-
 __device__ __forceinline__ void split_pair(const float (&v)[8], int e, bf16x8& h, bf16x8& m, bf16x8& l) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -463,10 +456,7 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
                                               float* lds) {
     constexpr int NT = 4 * NTW, KTT = KT + KT2, TILES = NT + KTT, J = KTT / GROUP, NM = 6 * NTW * GROUP;
     static_assert(TILES <= 16 && KTT % GROUP == 0 && (NTW + GROUP) * 3 <= NM, "shape");
-#ifndef NERF_PK_TAIL
-#define NERF_PK_TAIL 6
-#endif
-    constexpr int PTAIL = NERF_PK_TAIL;   // the last 1/PTAIL of a k-step's MFMAs carry no split work
+    constexpr int PTAIL = 6;   // the last 1/PTAIL of a k-step's MFMAs carry no split work
     const int i = lane & 31, s = lane >> 5;
     const int n0 = wave * NTW * 32;
     f32x16 acc[NTW][KTT];
@@ -654,18 +644,8 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
 
 // shape ids (NTW,KT,KT2,NW): 0 = <2,8,0,4>  1 = <1,8,1,4>  2 = <2,2,0,4>   (a 320-register <2,8,2> tile set does
 // not allocate without spills);  small layers of the hash-grid model: 3 = <1,1,0,2>  4 = <1,2,0,1>  5 = <1,1,1,2>
-#ifdef NERF_WG_TIMING
-__device__ unsigned long long g_wg_time[4096];
-extern "C" int nerf_debug_wg_times(unsigned long long* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_time), sizeof(g_wg_time));
-}
-#endif
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
-#ifdef NERF_WG_TIMING
-    const unsigned long long t_start = wall_clock64();
-    const unsigned long long c_start = clock64();
-#endif
     int pi = 0;
 #pragma unroll 1
     while (pi + 1 < parts.n && (int)blockIdx.x >= parts.part[pi + 1].first_block) ++pi;
@@ -677,31 +657,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     if (t0 >= t1) return;   // uniform for the whole workgroup
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     switch (pt.shape) {
-#if NERF_WGRAD_PK
         case 0: wgrad_part_pk<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 1: wgrad_part_pk<1, 8, 1, 3>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 2: wgrad_part_x6<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;   // 24 MFMAs per k-step cannot hide the loads of the shared split
-#elif NERF_WGRAD_X6
-        case 0: wgrad_part_x6<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        case 1: wgrad_part_x6<1, 8, 1, 3>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        case 2: wgrad_part_x6<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-#else
-        case 0: wgrad_part<2, 8, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        case 1: wgrad_part<1, 8, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        case 2: wgrad_part<2, 2, 0>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-#endif
         case 3: wgrad_part<1, 1, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 4: wgrad_part<1, 2, 0, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         default: wgrad_part<1, 1, 1, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
     }
-#ifdef NERF_WG_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 1024) {
-        g_wg_time[4 * blockIdx.x] = t_start;
-        g_wg_time[4 * blockIdx.x + 1] = wall_clock64();
-        g_wg_time[4 * blockIdx.x + 2] = c_start;
-        g_wg_time[4 * blockIdx.x + 3] = clock64();
-    }
-#endif
 }
 
 // Relative time per point of a workgroup of each shape (measured for the first three; the

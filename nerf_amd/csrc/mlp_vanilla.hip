@@ -2,9 +2,9 @@
 // FastMLPNeRF.forward, src/models/FastMLPNeRF.py:47-70).
 //
 // Forward: one wavefront per 32 points; positional encodings are computed in
-// registers, every layer is a chain of exact-f32 MFMAs whose accumulators become
+// registers, every layer is a chain of bf16 x 6 MFMAs (fp32-accurate) whose accumulators become
 // the next layer's B operands (see mlp_common.h), weights stream from the
-// packed buffer (L2-resident, 2.4 MB) through LDS, copied once per workgroup.  For training the activations are written
+// packed buffer (L2-resident, 7 MB) through LDS, copied once per workgroup.  For training the activations are written
 // row-major for the weight-gradient GEMMs plus one ReLU bit per neuron for the
 // backward-data kernel.
 // Backward: (1) a fused backward-data chain in the same register layout that
@@ -13,15 +13,8 @@
 #include "mlp_common.h"
 
 namespace nerf {
-// The dense layers of the forward and backward-data kernels run on bf16 x 6 MFMAs (dense_x6) when
-// this is set, on the exact-f32 MFMA (dense_shared) otherwise; both are fp32-accurate.
-#ifndef NERF_MLP_X6
-#define NERF_MLP_X6 1
-#endif
-constexpr bool MLP_X6 = NERF_MLP_X6 != 0;
-
 namespace vp {  // float offsets into the packed buffer
-constexpr int wfloats(int KT, int OT) { return MLP_X6 ? x6_layer_floats(KT, OT) : KT * 16 * 64 * OT; }
+constexpr int wfloats(int KT, int OT) { return x6_layer_floats(KT, OT); }
 constexpr int T88 = wfloats(8, 8);
 constexpr int F_L0 = 0;                     // 63(64) -> 256
 constexpr int F_L1 = F_L0 + wfloats(2, 8);  // layers 1,2,3
@@ -85,33 +78,15 @@ __device__ __forceinline__ void tile_index(long long P, TileIdx& ix) {
     ix.P32 = (P + 31) / 32 * 32;
 }
 
-constexpr NextChunks NO_CHUNKS{nullptr, 0, nullptr, 0};
-
-// One dense layer through the weight stream, in the flavour selected by MLP_X6.
+// One dense layer through the weight stream (bf16 x 6 MFMAs); the stream knows which layer comes next.
 template <int KT, int OT, bool DRAIN = false>
-__device__ __forceinline__ void dense_layer(WeightStream& ws, const float* __restrict__ wp, const NextChunks nx,
-                                            const f32x16 (&in)[KT], f32x16 (&acc)[OT],
+__device__ __forceinline__ void dense_layer(WeightStream& ws, const f32x16 (&in)[KT], f32x16 (&acc)[OT],
                                             TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
-    if constexpr (MLP_X6) dense_x6<KT, OT, DRAIN>(ws, in, acc, sv);   // the stream knows what comes next
-    else dense_shared<KT, OT, DRAIN>(ws, wp, nx, in, acc, sv);
+    dense_x6<KT, OT, DRAIN>(ws, in, acc, sv);
 }
-template <int OT_NEXT>
-__device__ __forceinline__ NextChunks chunks_after(const float* after) {
-    if constexpr (MLP_X6) return NO_CHUNKS;
-    else return next_chunks<OT_NEXT>(after);
-}
-__device__ __forceinline__ void stream_prime(WeightStream& ws, const float* first, const float* end) {   // a layer of 8 out tiles
-    if constexpr (MLP_X6) x6_prime(ws, first, end);
-    else ws_prime(ws, first, 8, first + WS_CHUNK_FLOATS, 8);
-}
-constexpr int STREAM_LDS_FLOATS = MLP_X6 ? X6_LDS_FLOATS : WS_LDS_FLOATS;
+constexpr int STREAM_LDS_FLOATS = X6_LDS_FLOATS;
 constexpr int HEAD_LDS_OFF = STREAM_LDS_FLOATS + 4 * TILE_LDS_FLOATS;
 constexpr int KERNEL_LDS_FLOATS = HEAD_LDS_OFF + vp::HEAD_FLOATS;
-// The chunks of the view-direction layer (1 in-tile, 4 out tiles): two k-steps of 12 KiB, or one chunk of 16 KiB.
-__device__ __forceinline__ NextChunks dir_chunks(const float* first) {
-    if constexpr (MLP_X6) return NO_CHUNKS;
-    else return NextChunks{first, 4, nullptr, 0};
-}
 
 template <bool SAVE>
 __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dirs,
@@ -128,7 +103,7 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     // the head weights (density row, rgb rows) go to LDS with the first chunks; complete after ws_ready()
     if (ix.wave < vp::HEAD_FLOATS / 256) ws_copy_piece(WeightStream{lds, 0, ix.wave, lane}, pk + vp::S_WS, lds + HEAD_LDS_OFF, 0);
     const unsigned heads = lds_addr(lds + HEAD_LDS_OFF);
-    stream_prime(wst, pk + vp::F_L0, pk + vp::B_RGB0);
+    x6_prime(wst, pk + vp::F_L0, pk + vp::B_RGB0);
     const float x0 = x[3 * ix.lp], x1 = x[3 * ix.lp + 1], x2 = x[3 * ix.lp + 2];
     uint4* mask_out = SAVE ? reinterpret_cast<uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane : nullptr;
 
@@ -148,26 +123,24 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     };
     // layer 0
     fill_rows<8>(acc, pk + vp::S_BIAS, h);
-    dense_layer<2, 8, SAVE>(wst, pk + vp::F_L0, chunks_after<8>(pk + vp::F_L1), xe, acc,
+    dense_layer<2, 8, SAVE>(wst, xe, acc,
                              tile_save(tb, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64));
     finish_layer(0);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
-        const float* wp = pk + vp::F_L1 + (l - 1) * vp::T88;   // followed by the next layer, or by the layer-4 x columns
         fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense_layer<8, 8, SAVE>(wst, wp, chunks_after<8>(wp + vp::T88), hc, acc, rows_of(vw::H + 256 * (l - 1)));
+        dense_layer<8, 8, SAVE>(wst, hc, acc, rows_of(vw::H + 256 * (l - 1)));
         finish_layer(l);
     }
     // skip connection: the layer-4 input is [x_enc | h] (either column order, see the packing)
     fill_rows<8>(acc, pk + vp::S_BIAS + 256 * 4, h);
-    dense_layer<2, 8>(wst, pk + vp::F_L4X, chunks_after<8>(pk + vp::F_L4H), xe, acc);
-    dense_layer<8, 8, SAVE>(wst, pk + vp::F_L4H, chunks_after<8>(pk + vp::F_L5), hc, acc, rows_of(vw::H + 256 * 3));
+    dense_layer<2, 8>(wst, xe, acc);
+    dense_layer<8, 8, SAVE>(wst, hc, acc, rows_of(vw::H + 256 * 3));
     finish_layer(4);
 #pragma unroll 1
     for (int l = 5; l < 8; ++l) {
-        const float* wp = pk + vp::F_L5 + (l - 5) * vp::T88;   // followed by the next layer, or by the feature layer
         fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense_layer<8, 8, SAVE>(wst, wp, chunks_after<8>(wp + vp::T88), hc, acc, rows_of(vw::H + 256 * (l - 1)));
+        dense_layer<8, 8, SAVE>(wst, hc, acc, rows_of(vw::H + 256 * (l - 1)));
         finish_layer(l);
     }
     // density head: softplus(w.h + b)   (NeRF.py:90)
@@ -175,15 +148,15 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(sp);
     // feature layer (no activation)      (NeRF.py:95)
     fill_rows<8>(acc, pk + vp::S_BF, h);
-    dense_layer<8, 8, SAVE>(wst, pk + vp::F_FEAT, chunks_after<4>(pk + vp::F_RGB0F), hc, acc, rows_of(vw::H + 256 * 7));
+    dense_layer<8, 8, SAVE>(wst, hc, acc, rows_of(vw::H + 256 * 7));
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
     const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
     pe_tiles<1, 4>(de, dirs[3 * dr], dirs[3 * dr + 1], dirs[3 * dr + 2], h);
     f32x16 hr[4];
     fill_rows<4>(hr, pk + vp::S_B1, h);
-    dense_layer<8, 4, SAVE>(wst, pk + vp::F_RGB0F, dir_chunks(pk + vp::F_RGB0D), acc, hr, rows_of(vw::FEAT));
-    dense_layer<1, 4, SAVE>(wst, pk + vp::F_RGB0D, NO_CHUNKS, de, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
+    dense_layer<8, 4, SAVE>(wst, acc, hr, rows_of(vw::FEAT));
+    dense_layer<1, 4, SAVE>(wst, de, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
     relu_tiles<4>(hr);
     if (SAVE) {
         save_tiles<4>(tb, ws + ix.P32 * vw::HR + ix.tile * 32 * 128, 128, hr);
@@ -209,7 +182,7 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
     const int lane = ix.lane, h = ix.h;
     WeightStream wst{lds, 0, ix.wave, lane};
     const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
-    stream_prime(wst, pk + vp::B_RGB0, pk + vp::S_BIAS);
+    x6_prime(wst, pk + vp::B_RGB0, pk + vp::S_BIAS);
     const uint4* mask_in = reinterpret_cast<const uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane;
     float dpre[3], dps = 0.0f;
 #pragma unroll
@@ -247,10 +220,10 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
     auto rows_of = [&](int section) { return tile_save(tb, ws2 + ix.P32 * section + ix.tile * 32 * 256); };
     f32x16 a[8], b[8];
     zero_tiles<8>(a);
-    dense_layer<4, 8, true>(wst, pk + vp::B_RGB0, chunks_after<8>(pk + vp::B_FEAT), dyr, a,
+    dense_layer<4, 8, true>(wst, dyr, a,
                              tile_save(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128));   // d feat
     zero_tiles<8>(b);
-    dense_layer<8, 8, true>(wst, pk + vp::B_FEAT, chunks_after<8>(pk + vp::B_L7), a, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
+    dense_layer<8, 8, true>(wst, a, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
 #pragma unroll
     for (int t = 0; t < 8; ++t)                    // ... plus the density head
 #pragma unroll
@@ -264,11 +237,8 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
     apply_bits<8>(b, mask_in[7 * 64]);
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                 // d h_{l-1} = W_l^T d y_l (h columns only at l = 4)
-        const float* wp = pk + vp::B_L7 + (7 - l) * vp::T88;
-        NextChunks nx = chunks_after<8>(wp + vp::T88);
-        if (l == 1) nx = NO_CHUNKS;
         zero_tiles<8>(a);
-        dense_layer<8, 8, true>(wst, wp, nx, b, a, rows_of(vw::DY + l * 256));
+        dense_layer<8, 8, true>(wst, b, a, rows_of(vw::DY + l * 256));
         apply_bits<8>(a, mask_in[(l - 1) * 64]);
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[t] = a[t];
@@ -330,7 +300,7 @@ extern "C" int nerf_mlp_vanilla_pack(const float* const* params, int skip_h_firs
     J.job[n++] = pack_bwd_job(Wf, 256, 256, vp::B_FEAT, 8, 8, 0, 256);
     for (int l = 7; l >= 1; --l)
         J.job[n++] = pack_bwd_job(Wl(l), l == 4 ? 319 : 256, 256, vp::B_L7 + (7 - l) * vp::T88, 8, 8, l == 4 ? h_col : 0, 256);
-    for (int i = 0; i < n; ++i) J.job[i].x6 = MLP_X6;   // every matrix above feeds a dense layer
+    for (int i = 0; i < n; ++i) J.job[i].x6 = 1;   // every matrix above feeds a dense layer
     for (int l = 0; l < 8; ++l) J.job[n++] = pack_copy_job(bl(l), vp::S_BIAS + 256 * l, 256);
     J.job[n++] = pack_copy_job(bf, vp::S_BF, 256);
     J.job[n++] = pack_copy_job(b1, vp::S_B1, 128);

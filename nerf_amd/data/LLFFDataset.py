@@ -2,7 +2,7 @@
 from __future__ import annotations
 
 from pathlib import Path
-from typing import Tuple
+from typing import List, Tuple
 
 import numpy as np
 import torch
@@ -10,62 +10,69 @@ from torch.utils.data import Dataset
 
 from ._images import load_array
 
+IMAGE_SUFFIXES = ("png", "jpg", "PNG", "JPG")   # the order the reference concatenates its globs in
+TARGET_WIDTH = 100                               # images wider than this are shrunk to it (src/data/LLFFDataset.py:62)
+
 
 def read_poses_bounds(path) -> Tuple[np.ndarray, np.ndarray, float]:
     """``poses_bounds.npy`` [N,17] -> poses [N,3,5] (3x4 pose | (H, W, focal) column), bounds [N,2] and the
     focal length of the first frame (src/data/LLFFDataset.py:24-27)."""
-    poses_bounds = np.load(path)
-    poses = poses_bounds[:, :-2].reshape([-1, 3, 5])
-    bounds = poses_bounds[:, -2:]
-    return poses, bounds, poses[0, -1, -1]
+    table = np.load(path)
+    poses = table[:, :15].reshape(-1, 3, 5)
+    return poses, table[:, 15:], poses[0, 2, 4]
+
+
+def list_frames(image_dir: Path) -> List[Path]:
+    """Image files of a scene directory, per suffix in sorted order (src/data/LLFFDataset.py:30-36)."""
+    if not image_dir.exists():
+        raise FileNotFoundError(f"Image directory {image_dir} not found.")
+    frames = [p for suffix in IMAGE_SUFFIXES for p in sorted(image_dir.glob("*." + suffix))]
+    if not frames:
+        raise FileNotFoundError(f"No images found in {image_dir}")
+    return frames
+
+
+def split_indices(total: int, split: str) -> np.ndarray:
+    """The reference holds out nothing: 'train' is every frame, 'val' is empty (src/data/LLFFDataset.py:43-54)."""
+    if split not in ("train", "val"):
+        raise ValueError(f"Unknown split: {split}")
+    return np.arange(total if split == "train" else 0)
+
+
+def shrink_transposed(images: torch.Tensor, scale: float) -> torch.Tensor:
+    """[N,H,W,3] -> [N,W',H',3] with H' = int(H scale), W' = int(W scale): bilinear with antialiasing (what
+    torchvision does to a tensor image), and the reference's permute(2, 1, 0) that leaves the result
+    width-major (src/data/LLFFDataset.py:66-75)."""
+    n, h, w, _ = images.shape
+    small = torch.nn.functional.interpolate(images.permute(0, 3, 1, 2), size=(int(h * scale), int(w * scale)),
+                                            mode="bilinear", align_corners=False, antialias=True)
+    return small.permute(0, 3, 2, 1).contiguous()
 
 
 class LLFFDataset(Dataset):
     """Same constructor, fields and items as the reference class (src/data/LLFFDataset.py:9-86): an item is
-    (image, pose [3,4], focal, H, W, bounds [2]).  Like the reference, every frame is a training frame
-    (its validation list is empty), images wider than 100 pixels are resized to width 100 and come back
-    transposed ([W,H,3], the reference's permute(2, 1, 0)), and the focal length is left unscaled."""
+    (image, pose [3,4], focal, H, W, bounds [2]).  The reference's quirks are kept: every frame is a training
+    frame, shrunk images come back transposed, and the focal length is left unscaled (its rescale statement
+    sits inside a comment, :75)."""
+
+    near, far = 2.0, 6.0
 
     def __init__(self, scene_dir, split="train", factor=8):
-        self.scene_dir = Path(scene_dir)
-        self.split = split
-        self.factor = factor
-        self.near = 2.0
-        self.far = 6.0
-        self.poses, self.bounds, self.focal = read_poses_bounds(self.scene_dir / "poses_bounds.npy")
-        image_dir = self.scene_dir / f"images_{factor}"
-        if not image_dir.exists():
-            raise FileNotFoundError(f"Image directory {image_dir} not found.")
-        image_paths = (sorted(image_dir.glob("*.png")) + sorted(image_dir.glob("*.jpg")) +
-                       sorted(image_dir.glob("*.PNG")) + sorted(image_dir.glob("*.JPG")))
-        if not image_paths:
-            raise FileNotFoundError(f"No images found in {image_dir}")
-        images = np.stack([load_array(p) / 255.0 for p in image_paths], axis=0)   # [N,H,W,3]
-        self.images = torch.from_numpy(images).float()
-        total = len(self.images)
-        if split == "train":
-            self.indices = np.arange(total)
-        elif split == "val":
-            self.indices = np.arange(0)
-        else:
-            raise ValueError(f"Unknown split: {split}")
-        self.poses = self.poses[self.indices]
-        self.images = self.images[self.indices]
-        self.H, self.W = self.images.shape[1:3]
-        self.resize_factor = 100 / self.W
+        self.scene_dir, self.split, self.factor = Path(scene_dir), split, factor
+        poses, bounds, self.focal = read_poses_bounds(self.scene_dir / "poses_bounds.npy")
+        frames = list_frames(self.scene_dir / f"images_{factor}")
+        pixels = torch.from_numpy(np.stack([load_array(f) / 255.0 for f in frames])).float()   # [N,H,W,3]
+        self.indices = split_indices(len(pixels), split)
+        self.poses, self.bounds, self.images = poses[self.indices], bounds, pixels[self.indices]
+        self.H, self.W = (int(v) for v in self.images.shape[1:3])
+        self.resize_factor = TARGET_WIDTH / self.W
         if self.resize_factor < 1.0:
-            new_H = int(self.H * self.resize_factor)
-            new_W = int(self.W * self.resize_factor)
-            # bilinear with antialiasing, as torchvision resizes a tensor image
-            resized = torch.nn.functional.interpolate(self.images.permute(0, 3, 1, 2), size=(new_H, new_W),
-                                                      mode="bilinear", align_corners=False, antialias=True)
-            self.images = resized.permute(0, 3, 2, 1).contiguous()   # [N,W,H,3], see the class note
-            self.H = int(self.H * self.resize_factor)
-            self.W = int(self.W * self.resize_factor)
+            self.images = shrink_transposed(self.images, self.resize_factor)
+            self.H, self.W = int(self.H * self.resize_factor), int(self.W * self.resize_factor)
 
     def __len__(self):
         return len(self.images)
 
     def __getitem__(self, idx):
-        pose = self.poses[idx, :3, :4]
-        return self.images[idx], torch.from_numpy(pose).float(), self.focal, self.H, self.W, self.bounds[idx]
+        return (self.images[idx], torch.from_numpy(self.poses[idx, :3, :4]).float(), self.focal, self.H, self.W,
+                self.bounds[idx])

@@ -147,9 +147,19 @@ class _HashGrid(torch.autograd.Function):
         res, sizes, shapes = ctx.meta
         g = L.f32c(d_out)
         grads = [torch.zeros(s, device=xc.device) for s in shapes]
+        work, nbytes = scatter_workspace(xc.shape[0], sizes, xc.device)
         L.check(L.lib().nerf_hashgrid_bwd(L.ptr(xc), xc.shape[0], L.ptr(g), L.int_array(res), L.int_array(sizes),
-                                          len(res), L.ptr_array(grads), L.stream_of(xc)), "nerf_hashgrid_bwd")
+                                          len(res), L.ptr_array(grads), L.ptr(work), nbytes, L.stream_of(xc)),
+                "nerf_hashgrid_bwd")
         return (None, None, None, *grads)
+
+
+def scatter_workspace(P: int, sizes, device):
+    """Scratch for the binned table-gradient scatter (None, 0 when the batch is too small to bin)."""
+    nbytes = L.lib().nerf_hashgrid_bwd_workspace_bytes(P, L.int_array(sizes), len(sizes))
+    if not nbytes:
+        return None, 0
+    return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
 
 
 def hashgrid_encode(x: torch.Tensor, tables: Sequence[torch.Tensor], res: Sequence[int]) -> torch.Tensor:
@@ -408,10 +418,11 @@ class _NgpMLP(torch.autograd.Function):
         d_rgb = L.f32c(d_rgb) if d_rgb is not None else torch.zeros(P, 3, device=dev)
         d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, device=dev)
         ws2 = torch.empty(_ceil32(P) * lib.nerf_mlp_ngp_ws2_floats_per_point(), device=dev)
+        work, nbytes = scatter_workspace(P, sizes, dev)
         L.check(lib.nerf_mlp_ngp_bwd(L.ptr(xc), L.ptr(d_rgb), L.ptr(d_sigma), P, L.int_array(res), L.int_array(sizes),
                                      L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(ws2),
-                                     L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.stream_of(rgb)),
-                "nerf_mlp_ngp_bwd")
+                                     L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.ptr(work), nbytes,
+                                     L.stream_of(rgb)), "nerf_mlp_ngp_bwd")
         return (None, None, None, None, None, *grads)
 
 

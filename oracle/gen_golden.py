@@ -311,13 +311,15 @@ def g8():
 
 
 # ---------------------------------------------------------------- G9 training trajectory, 100x100 / 64 samples
-def g9(steps=320):
+def g9(steps=320, ckpt=None):
     """The reference's own pieces trained on the analytic scene at the size of its synthetic trainer
     (src/train_nerf.py:91-92: 100 x 100 rays, 64 samples; 40 views on a circle, :53-54): NeRF() from
     torch.manual_seed(0), Camera.sample_points_along_rays(perturb=True) under torch.manual_seed(1000 + step),
     chunked model calls, Camera.volume_render, mse_loss, clip_grad_norm_(1.0) (:165), Adam(lr=5e-4) (:86).
     Recorded: loss of every step, PSNR of a held-out view at a few step counts.  The ground-truth images are
-    not stored (the far side re-renders the analytic field); their checksums are."""
+    not stored (the far side re-renders the analytic field); their checksums are.  ``ckpt``: a file to
+    checkpoint to every 10 steps and resume from (the run takes an hour; every step reseeds the generator,
+    so a resumed run is the same run)."""
     import time
     H = W = 100
     n, near, far, boost = 64, 1.0, 5.0, 5.0
@@ -362,8 +364,15 @@ def g9(steps=320):
     model = NeRF()
     opt = torch.optim.Adam(model.parameters(), lr=5e-4)
     losses, norms, marks, psnrs = [], [], [], []
+    first = 0
+    if ckpt and os.path.exists(ckpt):
+        st = torch.load(ckpt, weights_only=True)
+        model.load_state_dict(st["model"])
+        opt.load_state_dict(st["opt"])
+        losses, norms, marks, psnrs, first = st["losses"], st["norms"], st["marks"], st["psnrs"], st["step"]
+        print("resumed at step", first, flush=True)
     t0 = time.time()
-    for step in range(steps):
+    for step in range(first, steps):
         v = step % 40
         torch.manual_seed(1000 + step)
         with contextlib.redirect_stdout(io.StringIO()):   # NeRF.forward prints on NaN
@@ -380,6 +389,10 @@ def g9(steps=320):
             marks.append(step + 1)
             psnrs.append(psnr(held, imgs[40]))
             print(f"step {step + 1}: loss {losses[-1]:.6f} held-out psnr {psnrs[-1]:.3f} ({time.time() - t0:.0f}s)", flush=True)
+        if ckpt and (step + 1) % 10 == 0:
+            torch.save({"model": model.state_dict(), "opt": opt.state_dict(), "losses": losses, "norms": norms,
+                        "marks": marks, "psnrs": psnrs, "step": step + 1}, ckpt + ".tmp")
+            os.replace(ckpt + ".tmp", ckpt)
     save("g9_train.npz", c2w=torch.stack([c.c2w for c in cams]), cfg=np.array([H, W, focal[0], near, far, n, boost]),
          img_sum=np.array([float(i.double().sum()) for i in imgs]), img_sample=torch.stack([i[::10, ::10] for i in imgs]),
          loss=np.array(losses), grad_norm=np.array(norms), psnr_steps=np.array(marks), psnr=np.array(psnrs))
