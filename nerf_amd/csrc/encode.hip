@@ -53,44 +53,46 @@ __global__ __launch_bounds__(PE_THREADS) void encode_pe_kernel(const float* __re
 }
 
 // ----------------------------------------------------------- hash grid ----
-// grid.y = level, one thread per point: a workgroup gathers from one table, so
-// the small tables stay in L2 and the large ones in the Infinity Cache.
-__global__ void hashgrid_fwd_kernel(const float* __restrict__ x, int64_t P, HashLevels lv, int levels,
-                                    float* __restrict__ out, int32_t* __restrict__ idx_dump,
-                                    float* __restrict__ w_dump) {
-    const int l = blockIdx.y;
+// grid.y = a group of HG_FWD_GROUP consecutive levels, one thread per point: a workgroup gathers from a few
+// tables, so the small ones stay in L2 and the large ones in the Infinity Cache, and a thread writes its
+// group's features as one 32-byte piece of the point's row (8 bytes per level written one level at a time
+// cost four times the bytes at the memory side: a 32-byte sector is the unit of a partial write).
+constexpr int HG_FWD_GROUP = 4;
+__global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restrict__ x, int64_t P, HashLevels lv, int levels,
+                                                           float* __restrict__ out, int32_t* __restrict__ idx_dump,
+                                                           float* __restrict__ w_dump) {
+    const int l0 = blockIdx.y * HG_FWD_GROUP;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    const Cell c = locate(x, p, lv.res[l]);
-    const float2* __restrict__ tab = reinterpret_cast<const float2*>(lv.table[l]);
-    float2 f[8];
+    float2 r[HG_FWD_GROUP];
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {  // 000,001,...,111 = (x,y,z) offsets
-        const unsigned row = hash_row((corner & 4) ? c.hi[0] : c.lo[0], (corner & 2) ? c.hi[1] : c.lo[1],
-                                      (corner & 1) ? c.hi[2] : c.lo[2], lv.size[l]);
-        f[corner] = tab[row];
-        if (idx_dump) idx_dump[((int64_t)l * 8 + corner) * P + p] = (int32_t)row;
-    }
-    if (w_dump) {
+    for (int k = 0; k < HG_FWD_GROUP; ++k) {
+        const int l = l0 + k;
+        if (l >= levels) break;
+        const Cell c = locate(x, p, lv.res[l]);
+        const float2* __restrict__ tab = reinterpret_cast<const float2*>(lv.table[l]);
+        float2 f[8];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) w_dump[((int64_t)l * P + p) * 3 + k] = c.w[k];
-    }
-    const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
-    float r[2];
+        for (int corner = 0; corner < 8; ++corner) {  // 000,001,...,111 = (x,y,z) offsets
+            const unsigned row = corner_row(c, corner, lv.size[l]);
+            f[corner] = tab[row];
+            if (idx_dump) idx_dump[((int64_t)l * 8 + corner) * P + p] = (int32_t)row;
+        }
+        if (w_dump) {
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-        const float v000 = ch ? f[0].y : f[0].x, v001 = ch ? f[1].y : f[1].x, v010 = ch ? f[2].y : f[2].x,
-                    v011 = ch ? f[3].y : f[3].x, v100 = ch ? f[4].y : f[4].x, v101 = ch ? f[5].y : f[5].x,
-                    v110 = ch ? f[6].y : f[6].x, v111 = ch ? f[7].y : f[7].x;
-        const float x00 = v000 * (1.0f - wx) + v100 * wx;  // :95-98
-        const float x01 = v001 * (1.0f - wx) + v101 * wx;
-        const float x10 = v010 * (1.0f - wx) + v110 * wx;
-        const float x11 = v011 * (1.0f - wx) + v111 * wx;
-        const float y0 = x00 * (1.0f - wy) + x10 * wy;      // :100-101
-        const float y1 = x01 * (1.0f - wy) + x11 * wy;
-        r[ch] = y0 * (1.0f - wz) + y1 * wz;                 // :103
+            for (int j = 0; j < 3; ++j) w_dump[((int64_t)l * P + p) * 3 + j] = c.w[j];
+        }
+        r[k] = trilerp(f, c.w);   // src/utils/hash_grid_encoder.py:95-103
     }
-    *reinterpret_cast<float2*>(out + p * (2 * levels) + 2 * l) = make_float2(r[0], r[1]);
+    float* dst = out + p * (2 * levels) + 2 * l0;
+    if (l0 + HG_FWD_GROUP <= levels && (2 * levels) % 8 == 0) {
+        *reinterpret_cast<float4*>(dst) = make_float4(r[0].x, r[0].y, r[1].x, r[1].y);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(r[2].x, r[2].y, r[3].x, r[3].y);
+    } else {
+#pragma unroll
+        for (int k = 0; k < HG_FWD_GROUP; ++k)
+            if (l0 + k < levels) *reinterpret_cast<float2*>(dst + 2 * k) = r[k];
+    }
 }
 
 // d table[row(corner)][f] += weight(corner) * d_out[f], weight = product of (w or 1-w).
@@ -372,8 +374,9 @@ extern "C" int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* 
         NERF_REQUIRE(tables[l], "nerf_hashgrid_fwd: table %d is null", l);
         lv.table[l] = tables[l];
     }
-    hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3((unsigned)ceil_div(P, 256), levels), dim3(256), 0, (hipStream_t)stream, x,
-                       P, lv, levels, out, idx_dump, w_dump);
+    NERF_REQUIRE((size_t)out % 16 == 0, "nerf_hashgrid_fwd: out must be 16-byte aligned");
+    hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3((unsigned)ceil_div(P, 256), (unsigned)ceil_div(levels, HG_FWD_GROUP)),
+                       dim3(256), 0, (hipStream_t)stream, x, P, lv, levels, out, idx_dump, w_dump);
     return check_launch("nerf_hashgrid_fwd");
 }
 

@@ -181,7 +181,8 @@ inline size_t sample_lds_bytes(int N) { return (SMP_BLOCK + (size_t)(SMP_BLOCK /
 // ---------------------------------------------------------------------------
 // Hierarchical sampling: one wavefront per ray, 4 rays per workgroup; the waves
 // never meet (each works in its own LDS region, and LDS operations of one wave
-// complete in order).  Per ray: log-step scan of the 62 interior weights, a binary
+// complete in order).  Per ray: log-step scan of the 62 interior weights (in registers by wavefront
+// shuffles when they fit one per lane), a binary
 // search per fine sample, a bitonic sort of the fine depths in registers (EPL per
 // lane), and a merge with the already sorted coarse depths by rank: a coarse depth
 // moves up by the number of fine depths below it, a fine depth by the number of
@@ -252,24 +253,41 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
     const int nw = Nc - 2;  // interior weights
 
     for (int k = lane; k < Nc; k += 64) s_zc[wv][k] = zr[k];
-    for (int k = lane; k < nw; k += 64) s_scan[wv][0][k] = wr[k + 1] + 1e-5f;
-    wave_lds_sync();
-    for (int k = lane; k < nb; k += 64) s_bins[wv][k] = 0.5f * (s_zc[wv][k + 1] + s_zc[wv][k]);
-    // Log-step inclusive scan; the association order is part of the contract
-    // (the CPU oracle performs the same additions).
-    int cur = 0;
-    for (int dd = 1; dd < nw; dd <<= 1) {
-        for (int k = lane; k < nw; k += 64) {
-            const float v = s_scan[wv][cur][k];
-            s_scan[wv][cur ^ 1][k] = (k >= dd) ? v + s_scan[wv][cur][k - dd] : v;
+    float* cdf;
+    if (nw <= 64) {
+        // One weight per lane: the log-step inclusive scan runs in registers, each step one wavefront shuffle
+        // (lane k adds the value of lane k - d).  The association order is part of the contract: the CPU
+        // oracle performs the same additions.
+        float v = lane < nw ? wr[lane + 1] + 1e-5f : 0.0f;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const float below = __shfl_up(v, dd, 64);
+            if (lane >= dd) v = v + below;
         }
+        const float total = lane_value(v, nw - 1);
+        const float before = __shfl_up(v, 1, 64);   // c[k-1]
+        cdf = s_scan[wv][0];
+        if (lane < nb) cdf[lane] = lane == 0 ? 0.0f : before / total;   // cdf[0] = 0, cdf[k+1] = c[k] / total
         wave_lds_sync();
-        cur ^= 1;
+        for (int k = lane; k < nb; k += 64) s_bins[wv][k] = 0.5f * (s_zc[wv][k + 1] + s_zc[wv][k]);
+    } else {
+        for (int k = lane; k < nw; k += 64) s_scan[wv][0][k] = wr[k + 1] + 1e-5f;
+        wave_lds_sync();
+        for (int k = lane; k < nb; k += 64) s_bins[wv][k] = 0.5f * (s_zc[wv][k + 1] + s_zc[wv][k]);
+        // The same scan for more than 64 weights, through two LDS arrays.
+        int cur = 0;
+        for (int dd = 1; dd < nw; dd <<= 1) {
+            for (int k = lane; k < nw; k += 64) {
+                const float v = s_scan[wv][cur][k];
+                s_scan[wv][cur ^ 1][k] = (k >= dd) ? v + s_scan[wv][cur][k - dd] : v;
+            }
+            wave_lds_sync();
+            cur ^= 1;
+        }
+        const float total = s_scan[wv][cur][nw - 1];
+        cdf = s_scan[wv][cur ^ 1];
+        for (int k = lane; k < nb; k += 64) cdf[k] = (k == 0) ? 0.0f : s_scan[wv][cur][k - 1] / total;
     }
-    const float total = s_scan[wv][cur][nw - 1];
-    // cdf[0] = 0, cdf[k+1] = c[k] / total, stored in the other half of the ping-pong
-    float* cdf = s_scan[wv][cur ^ 1];
-    for (int k = lane; k < nb; k += 64) cdf[k] = (k == 0) ? 0.0f : s_scan[wv][cur][k - 1] / total;
     wave_lds_sync();
 
     float zf[EPL];
