@@ -63,6 +63,7 @@ def make_batch(rank: int, rays: int, dev):
 
 NGP_NEAR, NGP_FAR = 0.05, 1.2   # src/train_nerf_ngp.py:32-33 (unit-sphere-normalised poses)
 RAYS_SINGLE, RAYS_DP = 4096, 65536
+OVERLAP = os.environ.get("NERF_DP_OVERLAP", "1") != "0"   # all-reduce each bucket from its gradient hooks (under backward)
 NGP_WORKLOAD = ("Instant-NGP variant (16 levels, 2^19 rows, 64-wide MLPs), 800x800 camera on the unit sphere, 64 samples, "
                 "%d-ray batch per GPU, one training step incl. Adam over the tables")
 
@@ -89,7 +90,7 @@ def build_step(kind, rank, rays, dev, chunk_rays):
         torch.manual_seed(0)
         model = FastNGPNeRF().to(dev)
         buckets = GradBuckets([list(model.hash_encoder.parameters()),
-                               [p for n, p in model.named_parameters() if not n.startswith("hash_encoder")]])
+                               [p for n, p in model.named_parameters() if not n.startswith("hash_encoder")]], overlap=OVERLAP)
         opt = FusedAdam(buckets.parameters(), lr=1e-2, eps=1e-15)
         c2w = c2w.clone()
         c2w[:, 3] = c2w[:, 3] / 4.03
@@ -103,7 +104,7 @@ def build_step(kind, rank, rays, dev, chunk_rays):
         torch.manual_seed(1)
         fine = NeRF().to(dev)
         # backward reaches the fine model first: its bucket's all-reduce runs under the coarse model's backward
-        buckets = GradBuckets([list(fine.parameters()), list(model.parameters())])
+        buckets = GradBuckets([list(fine.parameters()), list(model.parameters())], overlap=OVERLAP)
         opt = FusedAdam(buckets.parameters(), lr=5e-4)   # torch.optim.Adam's update in one launch (tests/test_gpu_optim.py)
         z_lin = torch.linspace(NEAR, FAR, N_COARSE).to(dev)
         kw = dict(loss_fn=nerf_loss, white_bkgd=True, fine_model=fine, n_importance=N_FINE, u_fine=u_f)
@@ -148,10 +149,20 @@ def gpu_main(args):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # NERF_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share cards)
+    backend = os.environ.get("NERF_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        # first collective from this thread: communicator and its stream exist before any gradient hook uses them
+        warm = torch.zeros(1, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
     # one GPU: the 4096-ray batch the headline metric is quoted on; data parallel: 65,536 rays per GPU
     rays = args.rays if args.rays else (RAYS_SINGLE if world == 1 else RAYS_DP)
     chunk = args.chunk_rays
@@ -383,6 +394,9 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1024, help="ray sample of the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
+    if os.environ.get("NERF_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NERF_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", 1))
     if args.gpus > 1 and world == 1:
         # convenience: re-launch under torch.distributed.run (nothing has touched the GPU yet)

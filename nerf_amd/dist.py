@@ -47,7 +47,10 @@ class GradBuckets:
     Scale the loss by ``1 / world`` (``grad_scale``) to get the average.
     """
 
-    def __init__(self, buckets: Sequence, group=None):
+    def __init__(self, buckets: Sequence, group=None, overlap: bool = True):
+        """``overlap=False`` issues every bucket's all-reduce from ``finish()`` (the calling thread) instead of
+        from the gradient hooks: no overlap with backward, the plainest use of the process group."""
+        self.overlap = overlap
         if buckets and isinstance(buckets[0], torch.nn.Parameter):
             buckets = [list(buckets)]
         self.group = group
@@ -97,7 +100,7 @@ class GradBuckets:
             self._work[bi] = dist.all_reduce(self.flats[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _delivered(self, bi: int) -> None:
-        if not self._armed:
+        if not self._armed or not self.overlap:
             return
         self._missing[bi] -= 1
         if self._missing[bi] == 0 and not self._sent[bi]:
