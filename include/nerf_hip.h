@@ -211,10 +211,13 @@ int nerf_mlp_ngp_pack(const float* const* params, float* packed, void* stream);
 /* x [P,3]; dirs [ceil(P/dirs_div),3] un-normalised view directions (the kernel
  * normalises them like the model does) or NULL for "no directions" (colour input
  * zeros, src/models/FastNGPNeRF.py:100-103) -> rgb [P,3], sigma [P].
- * ws: ceil32(P)*ws_floats_per_point floats, or NULL for inference. */
+ * ws: ceil32(P)*ws_floats_per_point floats, or NULL for inference.
+ * enc: scratch of ceil32(P)*32 floats that receives the encoding level by level (two launches: the
+ * gather, every level on one XCD, then the MLPs). */
 int nerf_mlp_ngp_fwd(const float* x, const float* dirs, int dirs_div, int64_t P,
                      const float* const* tables, const int* res, const int* sizes,
-                     const float* packed, float* rgb, float* sigma, float* ws, void* stream);
+                     const float* packed, float* rgb, float* sigma, float* ws, float* enc,
+                     void* stream);
 /* Gradients of the 9 MLP parameters (`grads`, same order/shapes) and of the 16
  * tables (`d_tables`), all ACCUMULATED with float atomics: zero them first.
  * ws2: ceil32(P)*ws2_floats_per_point floats of scratch.  scatter_ws / scatter_ws_bytes: the

@@ -95,6 +95,27 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restri
     }
 }
 
+// The same gather with every level pinned to one XCD: workgroups whose linear id is congruent mod 8 share an
+// XCD and its 4 MiB L2, and a 2^19-row table is 4 MiB, so XCD g takes levels g, g + 8, ... one after the other
+// and its L2 holds the table being gathered from.  Output level-major, out_t[level][P][2]: consecutive lanes
+// write consecutive 8-byte features.
+template <bool LEVEL_MAJOR>
+__global__ __launch_bounds__(256) void hashgrid_fwd_pinned_kernel(const float* __restrict__ x, int64_t P, HashLevels lv,
+                                                                  int levels, int nblk, float* __restrict__ out,
+                                                                  int64_t level_stride) {
+    const int g = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int l = g + 8 * (i / nblk);
+    if (l >= levels) return;
+    const int64_t p = (int64_t)(i % nblk) * 256 + threadIdx.x;
+    if (p >= P) return;
+    const Cell c = locate(x, p, lv.res[l]);
+    float2 f[8];
+    gather_corners(lv.table[l], c, lv.size[l], f);
+    const float2 r = trilerp(f, c.w);   // src/utils/hash_grid_encoder.py:95-103
+    if (LEVEL_MAJOR) *reinterpret_cast<float2*>(out + 2 * ((int64_t)l * level_stride + p)) = r;
+    else *reinterpret_cast<float2*>(out + p * (2 * levels) + 2 * l) = r;
+}
+
 // d table[row(corner)][f] += weight(corner) * d_out[f], weight = product of (w or 1-w).
 // Scattered float atomics are executed line by line at the memory side, about 20 G lines/s
 // however few lanes of an instruction share a line.  Four lanes share a point: lane bit 0 is
@@ -361,6 +382,25 @@ static int fill_levels(const int* res, const int* sizes, int levels, int* res_ou
     return NERF_OK;
 }
 
+int nerf::launch_hashgrid_gather(const float* x, int64_t P, const float* const* tables, const int* res, const int* sizes,
+                                 int levels, float* out, bool level_major, int64_t level_stride, hipStream_t stream) {
+    HashLevels lv;
+    if (int rc = fill_levels(res, sizes, levels, lv.res, lv.size)) return rc;
+    for (int l = 0; l < levels; ++l) {
+        if (!tables[l]) return fail(NERF_EINVAL, "hashgrid: table %d is null", l);
+        lv.table[l] = tables[l];
+    }
+    const int64_t nblk = ceil_div(P, 256), grid = 8 * ceil_div(levels, 8) * nblk;
+    if (grid >= (1ll << 31)) return fail(NERF_EINVAL, "hashgrid: %lld points are too many for one launch", (long long)P);
+    if (level_major)
+        hipLaunchKernelGGL(hashgrid_fwd_pinned_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, x, P, lv, levels,
+                           (int)nblk, out, level_stride);
+    else
+        hipLaunchKernelGGL(hashgrid_fwd_pinned_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, x, P, lv, levels,
+                           (int)nblk, out, level_stride);
+    return check_launch("hashgrid_gather");
+}
+
 extern "C" int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* tables, const int* res,
                                  const int* sizes, int levels, float* out, int32_t* idx_dump, float* w_dump,
                                  void* stream) {
@@ -374,6 +414,8 @@ extern "C" int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* 
         NERF_REQUIRE(tables[l], "nerf_hashgrid_fwd: table %d is null", l);
         lv.table[l] = tables[l];
     }
+    if (!idx_dump && !w_dump)   // every level on one XCD; the grouped kernel below serves the parity dumps
+        return launch_hashgrid_gather(x, P, tables, res, sizes, levels, out, false, 0, (hipStream_t)stream);
     NERF_REQUIRE((size_t)out % 16 == 0, "nerf_hashgrid_fwd: out must be 16-byte aligned");
     hipLaunchKernelGGL(hashgrid_fwd_kernel, dim3((unsigned)ceil_div(P, 256), (unsigned)ceil_div(levels, HG_FWD_GROUP)),
                        dim3(256), 0, (hipStream_t)stream, x, P, lv, levels, out, idx_dump, w_dump);

@@ -91,6 +91,32 @@ __device__ __forceinline__ float2 trilerp(const float2 (&f)[8], const float (&w)
     return make_float2(r[0], r[1]);
 }
 
+// The eight corner rows of a cell, gathered in four 16-byte loads where that is possible: the hash is linear
+// in x, so the high-x corner of a (y, z) pair normally sits in the row after the low-x one.  Where it does not
+// (x wraps around the grid, or the sum wraps around the table) the high-x row is loaded by itself.
+// f[corner] in the reference's order, corner bits = (x, y, z) offsets.
+__device__ __forceinline__ void gather_corners(const float* __restrict__ table, const Cell& c, unsigned size, float2 (&f)[8],
+                                               unsigned (*rows)[8] = nullptr) {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+        const unsigned cy = (yz & 2) ? c.hi[1] : c.lo[1], cz = (yz & 1) ? c.hi[2] : c.lo[2];
+        const unsigned r_lo = hash_row(c.lo[0], cy, cz, size), r_hi = hash_row(c.hi[0], cy, cz, size);
+        if (rows) {
+            (*rows)[yz] = r_lo;
+            (*rows)[4 + yz] = r_hi;
+        }
+        if (r_hi == r_lo + 1) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(table + 2 * (size_t)r_lo);
+            f[yz] = make_float2(v[0], v[1]);
+            f[4 + yz] = make_float2(v[2], v[3]);
+        } else {
+            f[yz] = *reinterpret_cast<const float2*>(table + 2 * (size_t)r_lo);
+            f[4 + yz] = *reinterpret_cast<const float2*>(table + 2 * (size_t)r_hi);
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned corner_row(const Cell& c, int corner, unsigned size) {  // corner bits = (x,y,z) offsets
     return hash_row((corner & 4) ? c.hi[0] : c.lo[0], (corner & 2) ? c.hi[1] : c.lo[1], (corner & 1) ? c.hi[2] : c.lo[2], size);
 }
@@ -98,6 +124,11 @@ __device__ __forceinline__ float corner_weight(const Cell& c, int corner) {
     return (((corner & 4) ? c.w[0] : 1.0f - c.w[0]) * ((corner & 2) ? c.w[1] : 1.0f - c.w[1])) *
            ((corner & 1) ? c.w[2] : 1.0f - c.w[2]);
 }
+
+// The encoding of P points: out[p][2l + f] (row-major) or out[(l * level_stride + p) * 2 + f] (level-major); every
+// level is gathered by the workgroups of one XCD (defined with the encoder kernels).
+int launch_hashgrid_gather(const float* x, int64_t P, const float* const* tables, const int* res, const int* sizes, int levels,
+                           float* out, bool level_major, int64_t level_stride, hipStream_t stream);
 
 // d_tables[l][row][f] += corner weight * d_enc[p][2l + f] over all points and corners
 // (the backward of the hash-grid gather); defined with the encoder kernels.  With a workspace of

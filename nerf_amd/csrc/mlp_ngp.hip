@@ -3,8 +3,10 @@
 // (15+27 -> 64 -> 3 with the bias-free skip projection) in one kernel, the
 // 32-float encoding never leaves registers.
 //
-// One wavefront owns 32 points.  Lane (p, h) gathers and interpolates levels
-// 8h .. 8h+7 of point p (8 corner rows of 8 bytes each per level), which fills
+// The encoding is gathered first, level-major, by a launch that pins every level to one XCD (encode.hip:
+// a 4 MiB table then lives in that XCD's 4 MiB L2; gathered inside this kernel, where every wave walks all
+// 16 tables, the same loads took 2.7 times as long).  Then one wavefront owns 32 points.  Lane (p, h) reads
+// levels 8h .. 8h+7 of point p, which fills
 // the 16 registers of the first MFMA's B tile directly: register r of lane half
 // h is feature 16h + r, and the packed first-layer weight is permuted to match.
 // The backward kernel ends in the same layout, so each lane scatters the
@@ -45,16 +47,6 @@ constexpr int DENC = 164;   // [P32][32] gradient of the encoding, natural featu
 constexpr int PER_POINT2 = 196;
 }  // namespace nw
 
-struct NgpLevels {
-    const float* table[16];
-    int res[16];
-    unsigned size[16];
-};
-struct NgpGradLevels {
-    float* table[16];
-    int res[16];
-    unsigned size[16];
-};
 
 struct NgpIdx {
     long long tile, gp, lp, P32;
@@ -99,25 +91,19 @@ __device__ __forceinline__ void store16(float* __restrict__ dst, const f32x16& v
 }
 
 template <bool SAVE>
-__global__ __launch_bounds__(256) void ngp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dirs,
-                                                      int dirs_div, long long P, NgpLevels lv,
+__global__ __launch_bounds__(256) void ngp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
+                                                      int dirs_div, long long P,
                                                       const float* __restrict__ pk, float* __restrict__ rgb,
                                                       float* __restrict__ sigma, float* __restrict__ ws) {
     NgpIdx ix;
     if (!ngp_index(P, ix)) return;
     const int lane = ix.lane, h = ix.h;
-    // ---- hash encoding: levels 8h .. 8h+7 of this lane's point
+    // ---- hash encoding: levels 8h .. 8h+7 of this lane's point, gathered level by level by the launch before
+    // this one (enc: [16][P32][2]); 32 consecutive lanes read 256 contiguous bytes per level
     f32x16 e[1];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int res = h ? lv.res[8 + j] : lv.res[j];
-        const unsigned size = h ? lv.size[8 + j] : lv.size[j];
-        const float2* __restrict__ tab = reinterpret_cast<const float2*>(h ? lv.table[8 + j] : lv.table[j]);
-        const Cell c = locate(x, ix.lp, res);
-        float2 f[8];
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner) f[corner] = tab[corner_row(c, corner, size)];
-        const float2 v = trilerp(f, c.w);
+        const float2 v = *reinterpret_cast<const float2*>(enc + 2 * ((8 * h + j) * ix.P32 + ix.lp));
         e[0][2 * j] = v.x;
         e[0][2 * j + 1] = v.y;
     }
@@ -291,24 +277,19 @@ static int check_levels(const int* res, const int* sizes, const char* who) {
 
 extern "C" int nerf_mlp_ngp_fwd(const float* x, const float* dirs, int dirs_div, int64_t P, const float* const* tables,
                                 const int* res, const int* sizes, const float* packed, float* rgb, float* sigma,
-                                float* ws, void* stream) {
+                                float* ws, float* enc, void* stream) {
     if (P == 0) return NERF_OK;
-    NERF_REQUIRE(x && tables && res && sizes && packed && rgb && sigma, "nerf_mlp_ngp_fwd: null pointer");
+    NERF_REQUIRE(x && tables && res && sizes && packed && rgb && sigma && enc, "nerf_mlp_ngp_fwd: null pointer");
     NERF_REQUIRE(P >= 0 && dirs_div >= 1, "nerf_mlp_ngp_fwd: P=%lld dirs_div=%d", (long long)P, dirs_div);
     if (int rc = check_levels(res, sizes, "nerf_mlp_ngp_fwd")) return rc;
-    NgpLevels lv;
-    for (int l = 0; l < 16; ++l) {
-        NERF_REQUIRE(tables[l], "nerf_mlp_ngp_fwd: table %d is null", l);
-        lv.table[l] = tables[l];
-        lv.res[l] = res[l];
-        lv.size[l] = (unsigned)sizes[l];
-    }
+    const long long P32 = (P + 31) / 32 * 32;
+    if (int rc = launch_hashgrid_gather(x, P, tables, res, sizes, 16, enc, true, P32, (hipStream_t)stream)) return rc;
     const dim3 grid((unsigned)ceil_div(P, 128)), block(256);
     if (ws)
-        hipLaunchKernelGGL(ngp_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, dirs, dirs_div, (long long)P, lv,
+        hipLaunchKernelGGL(ngp_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, enc, dirs, dirs_div, (long long)P,
                            packed, rgb, sigma, ws);
     else
-        hipLaunchKernelGGL(ngp_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, dirs, dirs_div, (long long)P, lv,
+        hipLaunchKernelGGL(ngp_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, enc, dirs, dirs_div, (long long)P,
                            packed, rgb, sigma, ws);
     return check_launch("nerf_mlp_ngp_fwd");
 }

@@ -397,8 +397,9 @@ class _NgpMLP(torch.autograd.Function):
         sigma = torch.empty(P, device=dev)
         train = grad_mode and any(ctx.needs_input_grad[5:])   # see _VanillaMLP.forward
         ws = torch.empty(_ceil32(P) * lib.nerf_mlp_ngp_ws_floats_per_point(), device=dev) if train and P else None
+        enc = torch.empty(_ceil32(P) * 32, device=dev)   # the encoding, level-major, between the two launches
         L.check(lib.nerf_mlp_ngp_fwd(L.ptr(xc), L.ptr(dc), int(dirs_div), P, L.ptr_array(tabs), L.int_array(res),
-                                     L.int_array(sizes), L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), st),
+                                     L.int_array(sizes), L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(enc), st),
                 "nerf_mlp_ngp_fwd")
         if train:
             ctx.save_for_backward(xc, packed, rgb, sigma, ws)

@@ -372,7 +372,9 @@ def test_inference_under_no_grad_keeps_no_workspace(dev):
     P = 1 << 20
     x = torch.rand(P, 3, device=dev)
     dirs = torch.nn.functional.normalize(torch.randn(P, 3, device=dev), dim=-1)
-    for model in (NeRF().to(dev), FastNGPNeRF(log2_hashmap_size=14).to(dev)):
+    # NeRF: outputs 16 MB + packed weights; hash-grid model: + the 128 B/point encoding between its two launches
+    # (a training forward would keep 10.4 GB and 0.96 GB of activations)
+    for model, limit in ((NeRF().to(dev), 64 << 20), (FastNGPNeRF(log2_hashmap_size=14).to(dev), 192 << 20)):
         assert all(p.requires_grad for p in model.parameters())
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats(dev)
@@ -380,7 +382,7 @@ def test_inference_under_no_grad_keeps_no_workspace(dev):
         with torch.no_grad():
             rgb, sigma = model(x, dirs)
         torch.cuda.synchronize()
-        assert torch.cuda.max_memory_allocated(dev) - base < 64 << 20, type(model).__name__   # outputs 16 MB + packed weights
+        assert torch.cuda.max_memory_allocated(dev) - base < limit, type(model).__name__
         assert not rgb.requires_grad
         rgb2, _ = model(x[:4096], dirs[:4096])
         assert rgb2.requires_grad and torch.equal(rgb2.detach(), rgb[:4096])
