@@ -61,11 +61,15 @@ class GradBuckets:
         self.views: List[List[torch.Tensor]] = []
         self._hooks = []
         for bi, b in enumerate(self.buckets):
-            flat = torch.zeros(sum(p.numel() for p in b), device=b[0].device, dtype=torch.float32)
-            views, off = [], 0
+            # every view starts on a 256-byte boundary: the optimiser and clipping kernels read 16 bytes per lane
+            starts, off = [], 0
             for p in b:
-                views.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+                starts.append(off)
+                off += (p.numel() + 63) // 64 * 64
+            flat = torch.zeros(off, device=b[0].device, dtype=torch.float32)
+            views = []
+            for p, o in zip(b, starts):
+                views.append(flat[o:o + p.numel()].view_as(p))
                 self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._delivered(bi)))
             self.flats.append(flat)
             self.views.append(views)

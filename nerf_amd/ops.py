@@ -308,12 +308,12 @@ def vanilla_ws2(P: int, device) -> torch.Tensor:
 def zero_grads_like(shapes, device):
     """One zeroed flat buffer viewed as per-parameter gradients (a single memset)."""
     sizes = [int(torch.Size(s).numel()) for s in shapes]
-    flat = torch.zeros(sum(sizes), device=device)
-    out, off = [], 0
-    for s, n in zip(shapes, sizes):
-        out.append(flat[off:off + n].view(s))
-        off += n
-    return out
+    starts, off = [], 0
+    for n in sizes:   # 256-byte aligned views: these tensors become p.grad, which the optimiser reads 16 bytes per lane
+        starts.append(off)
+        off += (n + 63) // 64 * 64
+    flat = torch.zeros(off, device=device)
+    return [flat[o:o + n].view(s) for s, n, o in zip(shapes, sizes, starts)]
 
 
 class _VanillaMLP(torch.autograd.Function):
