@@ -57,6 +57,16 @@ def main():
 
     # outputs are allocated once and the C entry points called directly: at 20-50 us per kernel the
     # Python wrappers (allocation, autograd bookkeeping) would be what is timed
+    # what this chip sustains for plain streams of the same sizes (torch's fill and copy kernels): the practical
+    # ceilings next to the nominal 8 TB/s
+    for mb in (86, 304, 1107):
+        n = mb * 250000
+        a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        t = timeit(lambda: a.fill_(1.0))
+        report("reference: fill %d MB (write only)" % mb, 4 * n, t, "torch fill_")
+        t = timeit(lambda: b.copy_(a))
+        report("reference: copy %d MB (read + write)" % mb, 8 * n, t, "torch copy_")
+        del a, b
     lib = L.lib()
     st = L.stream_of(u)
     o, d, z, pts = ops.raygen_sample(c2w, f, f, 400.0, 400.0, 800, 800, pix, z_lin, u)

@@ -75,7 +75,7 @@ int nerf_raygen_sample(const float* c2w, float fx, float fy, float cx, float cy,
 
 /* Hierarchical inverse-CDF sampling (NeRF 2020 section 5.2).  The reference has
  * no such stage; the semantics are those of oracle/nerf_oracle.py:sample_pdf.
- * z [R,Nc], weights [R,Nc], u [R,Nf] -> z_fine [R,Nf], idx int32 [R,Nf] (may be
+ * z [R,Nc], weights [R,Nc], u [R,Nf] -> z_fine [R,Nf] (may be NULL), idx int32 [R,Nf] (may be
  * NULL), z_all [R,Nc+Nf] sorted, pts [R,Nc+Nf,3] (may be NULL).
  * Limits: 3 <= Nc <= 256, 1 <= Nf, Nc+Nf <= 1024. */
 int nerf_pdf_sample(const float* rays_o, const float* rays_d, const float* z, const float* weights,

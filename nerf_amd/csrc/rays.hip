@@ -91,10 +91,12 @@ __device__ __forceinline__ float stratified_depth(const float* __restrict__ z_li
     return lower + (upper - lower) * u[un];
 }
 
-// Four consecutive (ray, sample) pairs per thread, 1024 per workgroup.  The few rays a
-// workgroup touches are derived (RAYGEN: from the pixel) or loaded once into LDS, the depths
-// go through LDS too, and the points leave as fully coalesced 16-byte stores (flat float f
-// of the workgroup's span is coordinate f%3 of sample f/3).
+// Four consecutive (ray, sample) pairs per thread, 1024 per workgroup.  A thread derives the
+// ray(s) of its samples itself (RAYGEN: from the pixel, forty instructions; else a load) -- at
+// most two when N >= 4: one division finds the first, a comparison the switch -- forms its four
+// depths and twelve point coordinates in registers and parks the coordinates in LDS as 48
+// contiguous bytes, so that the points then leave as fully coalesced 16-byte stores (flat float
+// f of the workgroup's span is coordinate f%3 of sample f/3).  One barrier per workgroup.
 constexpr int SMP_THREADS = 256, SMP_PER_THREAD = 4, SMP_BLOCK = SMP_THREADS * SMP_PER_THREAD;
 template <bool RAYGEN>
 __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __restrict__ c2w, float fx, float fy, float cx,
@@ -104,79 +106,80 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
                                                              int64_t R, int N, float* __restrict__ rays_o,
                                                              float* __restrict__ rays_d, float* __restrict__ z_vals,
                                                              float* __restrict__ pts) {
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // depths, then (o, d) of the workgroup's rays
-    float* s_z = s_dyn;
-    float (*s_ray)[6] = reinterpret_cast<float (*)[6]>(s_dyn + SMP_BLOCK);
+    extern __shared__ __attribute__((aligned(16))) float s_pts[];   // the workgroup's 1024 points
     const int tid = threadIdx.x;
     const int64_t t0 = (int64_t)blockIdx.x * SMP_BLOCK, total = R * N;
-    const int64_t r_first = t0 / N;
-    const int n_first = (int)(t0 - r_first * N);                       // sample index of the block's first pair
     const int here = (int)min((int64_t)SMP_BLOCK, total - t0);         // pairs in this workgroup
-    const int rays_here = (int)((t0 + here - 1) / N - r_first) + 1;    // <= SMP_BLOCK + 1
-    for (int k = tid; k < rays_here; k += SMP_THREADS) {
-        const int64_t r = r_first + k;
-        float o[3], d[3];
-        if (RAYGEN) {
-            pixel_ray(c2w, fx, fy, cx, cy, W, pix ? pix[r] : (int)r, o, d);
-            if (k > 0 || n_first == 0) {   // the workgroup that holds a ray's first sample publishes the ray
+    const int first = SMP_PER_THREAD * tid;
+    const bool whole = first + SMP_PER_THREAD <= here;   // all four pairs exist: 16-byte accesses (t0 is a multiple of 1024)
+    const int64_t r_first = t0 / N;                      // the same for the whole workgroup
+    const int n_first = (int)(t0 - r_first * N);
+    const int k_first = (n_first + first) / N;           // 32-bit division: n_first < N, first < 1024
+    int64_t ray = r_first + k_first;                     // ray and sample index of the thread's first pair
+    int n = (n_first + first) - k_first * N;
+    float zz[4] = {0.f, 0.f, 0.f, 0.f}, pc[12];
+    if (first < here) {
+        float4 uu = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u && whole) uu = *reinterpret_cast<const float4*>(u + t0 + first);
+        const float ua[4] = {uu.x, uu.y, uu.z, uu.w};
+        float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (rays_o) rays_o[3 * r + c] = o[c];
-                    if (rays_d) rays_d[3 * r + c] = d[c];
+        for (int k = 0; k < 4; ++k) {
+            const bool exists = first + k < here;
+            if (exists && (k == 0 || n == 0)) {   // a new ray: derive it from its pixel (cheaper than a trip through LDS), or load it
+                if (RAYGEN) {
+                    pixel_ray(c2w, fx, fy, cx, cy, W, pix ? pix[ray] : (int)ray, o, d);
+                    if (n == 0) {   // the thread that holds a ray's first sample publishes the ray
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            if (rays_o) rays_o[3 * ray + c] = o[c];
+                            if (rays_d) rays_d[3 * ray + c] = d[c];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        o[c] = in_o[3 * ray + c];
+                        d[c] = in_d[3 * ray + c];
+                    }
                 }
             }
-        } else {
+            if (exists) zz[k] = whole ? stratified_depth(z_lin, N, n, u ? ua : nullptr, k)
+                                      : stratified_depth(z_lin, N, n, u, t0 + first + k);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                o[c] = in_o[3 * r + c];
-                d[c] = in_d[3 * r + c];
+            for (int c = 0; c < 3; ++c) pc[3 * k + c] = o[c] + d[c] * zz[k];   // src/Camera.py:140
+            if (++n == N) {   // the next pair starts the next ray
+                n = 0;
+                ++ray;
             }
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            s_ray[k][c] = o[c];
-            s_ray[k][3 + c] = d[c];
-        }
-    }
-    const int first = SMP_PER_THREAD * tid;
-    if (first + SMP_PER_THREAD <= here) {   // whole group of four: 16-byte accesses (t0 is a multiple of 1024)
-        float4 uu = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (u) uu = *reinterpret_cast<const float4*>(u + t0 + first);
-        const float ua[4] = {uu.x, uu.y, uu.z, uu.w};
-        float zz[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) zz[k] = stratified_depth(z_lin, N, (n_first + first + k) % N, u ? ua : nullptr, k);
-        const float4 zv = make_float4(zz[0], zz[1], zz[2], zz[3]);
-        if (z_vals) *reinterpret_cast<float4*>(z_vals + t0 + first) = zv;
-        *reinterpret_cast<float4*>(s_z + first) = zv;
-    } else {
-        for (int k = 0; k < SMP_PER_THREAD && first + k < here; ++k) {
-            const float zk = stratified_depth(z_lin, N, (n_first + first + k) % N, u, t0 + first + k);
-            if (z_vals) z_vals[t0 + first + k] = zk;
-            s_z[first + k] = zk;
+        if (z_vals) {
+            if (whole) *reinterpret_cast<float4*>(z_vals + t0 + first) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+            else
+                for (int k = 0; k < 4 && first + k < here; ++k) z_vals[t0 + first + k] = zz[k];
         }
     }
     if (!pts) return;
+    if (first < here) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            *reinterpret_cast<float4*>(s_pts + 12 * tid + 4 * j) = make_float4(pc[4 * j], pc[4 * j + 1], pc[4 * j + 2], pc[4 * j + 3]);
+    }
     __syncthreads();
-    auto point_coord = [&](int f) {
-        const int smp = f / 3, c = f - 3 * smp;
-        const int k = (n_first + smp) / N;
-        return s_ray[k][c] + s_ray[k][3 + c] * s_z[smp];   // src/Camera.py:140
-    };
     float* out = pts + t0 * 3;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int f = 4 * (j * SMP_THREADS + tid);
         if (f + 4 <= 3 * here) {
-            *reinterpret_cast<float4*>(out + f) = make_float4(point_coord(f), point_coord(f + 1), point_coord(f + 2), point_coord(f + 3));
+            *reinterpret_cast<float4*>(out + f) = *reinterpret_cast<const float4*>(s_pts + f);
         } else {
-            for (int k = 0; k < 4 && f + k < 3 * here; ++k) out[f + k] = point_coord(f + k);
+            for (int k = 0; k < 4 && f + k < 3 * here; ++k) out[f + k] = s_pts[f + k];
         }
     }
 }
 
-// LDS of a sample_kernel workgroup: 1024 depths and the rays its 1024 pairs can belong to.
-inline size_t sample_lds_bytes(int N) { return (SMP_BLOCK + (size_t)(SMP_BLOCK / N + 2) * 6) * sizeof(float); }
+// LDS of a sample_kernel workgroup: its 1024 points.
+inline size_t sample_lds_bytes(int) { return 3 * SMP_BLOCK * sizeof(float); }
 
 // ---------------------------------------------------------------------------
 // Hierarchical sampling: one wavefront per ray, 4 rays per workgroup; the waves

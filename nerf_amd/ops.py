@@ -89,14 +89,14 @@ def raygen_sample(c2w, fx, fy, cx, cy, H, W, pix, z_lin, u):
     return o, d, z, pts
 
 
-def pdf_sample(rays_o, rays_d, z, weights, u, want_idx: bool = False):
-    """Inverse-CDF fine sampling -> z_fine [R,Nf], idx int32 [R,Nf] | None, z_all [R,Nc+Nf], pts [R,Nc+Nf,3]."""
+def pdf_sample(rays_o, rays_d, z, weights, u, want_idx: bool = False, want_fine: bool = True):
+    """Inverse-CDF fine sampling -> z_fine [R,Nf] | None, idx int32 [R,Nf] | None, z_all [R,Nc+Nf], pts [R,Nc+Nf,3]."""
     L.need_gpu(rays_o, rays_d, z, weights, u)
     o, d, z, w, u = (L.f32c(t) for t in (rays_o, rays_d, z, weights.detach(), u))
     R, Nc = z.shape
     Nf = u.shape[1]
     dev = z.device
-    zf = torch.empty(R, Nf, device=dev)
+    zf = torch.empty(R, Nf, device=dev) if want_fine else None
     idx = torch.empty(R, Nf, device=dev, dtype=torch.int32) if want_idx else None
     z_all = torch.empty(R, Nc + Nf, device=dev)
     pts = torch.empty(R, Nc + Nf, 3, device=dev)

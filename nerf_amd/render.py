@@ -83,7 +83,7 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
     if fine_model is not None and n_importance > 0:
         if u_fine is None:
             u_fine = torch.rand(R, n_importance, device=dev)
-        _, _, z_all, pts_f = ops.pdf_sample(rays_o, rays_d, z, w, u_fine)
+        _, _, z_all, pts_f = ops.pdf_sample(rays_o, rays_d, z, w, u_fine, want_fine=False)
         rgb_f, sigma_f = _eval_model(fine_model, pts_f, view_dirs, n_samples + n_importance)
         if density_grid is not None:
             sigma_f = ops.occupancy_mask(sigma_f, pts_f, density_grid, grid_res)
@@ -202,7 +202,7 @@ def render_image(model, rays_o, rays_d, near: float, far: float, n_samples: int 
             c_map, w, dep = ops.composite(rgb, sigma, z, white_bkgd)
             if fine_model is not None and n_importance > 0:
                 u = torch.linspace(0.0, 1.0, n_importance, device=dev).expand(o.shape[0], n_importance).contiguous()
-                _, _, z, pts = ops.pdf_sample(o, d, z, w, u)
+                _, _, z, pts = ops.pdf_sample(o, d, z, w, u, want_fine=False)
                 rgb, sigma = _eval_model(fine_model, pts, view_dirs, n_samples + n_importance)
                 if density_grid is not None:
                     sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
