@@ -1,4 +1,4 @@
-// Building blocks of the fused MLP kernels (gfx950, exact-f32 MFMA).
+// Building blocks of the fused MLP kernels (gfx950; exact-f32 and split-f16 MFMA).
 //
 // Data layout idea.  v_mfma_f32_32x32x2_f32 computes D[32x32] += A[32x2] B[2x32]:
 //   A: lane l holds A[i = l&31][k = l>>5]      B: lane l holds B[k = l>>5][j = l&31]
@@ -124,7 +124,7 @@ __device__ __forceinline__ TileBuf tile_buf(float* lds_wave, int lane) {
     return TileBuf{lds_addr(lds_wave + (lane & 31) * TILE_LD + 4 * (lane >> 5)),
                    lds_addr(lds_wave + (lane >> 3) * TILE_LD + 4 * (lane & 7)), lane >> 3, 4 * (lane & 7)};
 }
-// Rows to write underneath a dense_x6() call: its input tiles, to rows0[32][ld].
+// Rows to write underneath a dense_h3() call: its input tiles, to rows0[32][ld].
 struct TileSave {
     TileBuf tb;
     float* rows0;   // row 0 of the tile's 32 rows, already offset by this lane's (row, col)
@@ -169,36 +169,290 @@ __device__ __forceinline__ void ws_ready() {
     __builtin_amdgcn_s_barrier();
 }
 
-// ------------------------------------------------------ bf16 x 6 dense ----
-// The same contraction at 2.6 times the rate of the exact-f32 MFMA and the same accuracy
-// (measured: max error / sum|terms| 1.3e-7 for K = 256, both): every fp32 operand is
-// split into three bf16 numbers, v = h + m + l with |m| <= 2^-9 |v| and |l| <= 2^-18 |v|,
-// and a product is the six bf16 MFMAs that matter (hh, hm, mh, mm, hl, lh; the rest is
-// below 2^-26), smallest terms first, accumulated in fp32 by v_mfma_f32_32x32x16_bf16
-// (2.5 PFLOP/s dense: 16x the fp32 matrix rate, so 6 of them cost 3/8 of one fp32 MFMA
-// pass over the same K).  The weights are split once per optimiser step by the pack
-// kernel; the activations on the fly, in the shadow of the previous k-step's MFMAs.
+// ------------------------------------------------------- f16 x 3 dense ----
+// The same contraction at five times the rate of the exact-f32 MFMA and fp32 accuracy (measured: max error /
+// sum|terms| 0.5-1.5e-7 at K = 256, an fp32 fma chain 1.3-3.7e-7): every fp32 operand is two f16 numbers,
+// v = h + l with h = f16(v) and l = f16(v - h), which together hold 22-24 bits of v as long as neither piece
+// leaves the f16 range (normal numbers 6e-5 .. 65504; subnormal inputs pass through the MFMA unflushed, with
+// an absolute error of 2^-25).  A product is the three f16 MFMAs that matter, a_h b_h + a_h b_l + a_l b_h (a_l b_l
+// is below 2^-22), accumulated in fp32 by v_mfma_f32_32x32x16_f16.  The residuals are kept in range by powers of
+// two: the weights store l' = 2^11 (w - h), the activations supply h'' = 2^-11 h next to h, so that
+// (a_l') (b_h'') = a_l b_h; and every point's activation vector is scaled by 2^e, chosen so that its largest
+// entry lies in [2^13, 2^14), which the epilogue of the layer removes again (PointScale).  Entries smaller than
+// 2^-17 of the largest lose relative, not absolute, accuracy: error / largest entry stays below 2^-38.
+// The weights are split once per optimiser step by the pack kernel; the activations on the fly, in the shadow of
+// the previous k-step's MFMAs.
 //
-// A k-step is K = 16: the B operand of lane (point p, half h) is eight of its registers
-// of the input tile (r = 8u..8u+7 for k-step 2t+u), i.e. neurons 32t + rowmap(r, h); the
-// packed weights follow the same order: x6[k-step][out tile][split][lane][8 bf16], one
-// k-step = 3 KiB per out tile = one chunk of the weight stream.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int X6_CHUNK_FLOATS = 8 * 3 * 256;              // largest chunk: a k-step of 8 out tiles (24 KiB)
-constexpr int x6_layer_floats(int KT, int OT) { return 2 * KT * OT * 3 * 256; }
-
-__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 hh = (__bf16)v[i];
-        const float r1 = v[i] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        h[i] = hh;
-        m[i] = mm;
-        l[i] = (__bf16)(r1 - (float)mm);
-    }
-}
+// A k-step is K = 16: the B operand of lane (point p, half h) is eight of its registers of the input tile
+// (r = 8u..8u+7 for k-step 2t+u), i.e. neurons 32t + rowmap(r, h); the packed weights follow the same order:
+// h3[k-step][out tile][piece h, l'][lane][8 f16], one k-step = 2 KiB per out tile.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int H3_CHUNK_FLOATS = 8 * 2 * 256;              // a chunk: a k-step of 8 out tiles, or two of 4 (16 KiB)
+constexpr int h3_layer_floats(int KT, int OT) { return 2 * KT * OT * 2 * 256; }
+
+// The three conversions below are volatile asm: left to the scheduler they drift between an asm LDS read and the
+// wait that completes it, where the extra register pressure makes the compiler copy registers whose data has
+// not arrived yet.
+// {f16(a), f16(b)} rounded to nearest even, a in the low half
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+    unsigned r;
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// x - (low or high half of hp as f32): exact in fp32 when that half is f16(x)
+template <int HALF>
+__device__ __forceinline__ float sub_f16(float x, unsigned hp) {
+    float r;
+    if constexpr (HALF == 0) asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+    else asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(x));
+    return r;
+}
+// both f16 halves times 2^-11 (exact unless the result is subnormal)
+__device__ __forceinline__ unsigned pk_f16_down11(unsigned hp) {
+    unsigned r;
+    asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(r) : "v"(hp), "v"(0x10001000u));
+    return r;
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ f16x8 lds_read_h8(unsigned addr) {
+    f16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF_BYTES));
+    return r;
+}
+
+// The power of two that brings a point's activation vector into the f16 pieces' range, and its inverse.
+struct PointScale {
+    float s, inv;
+};
+// Lanes l and l ^ 32 exchange a value without LDS (a cross-lane LDS operation known to the compiler would wait
+// for every weight copy in flight): after the swap a holds lane l's value in the low half and lane l-32's in the
+// high half, b the reverse, so a (op) b combines the pair in both lanes.
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+    // the builtin, not asm: the instruction needs wait states after a VALU write of its operands, which the compiler
+    // only inserts for instructions it knows
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+// m: the largest |entry| this lane holds; the other half of the point's vector is in lane ^ 32.
+__device__ __forceinline__ PointScale point_scale(float m) {
+    float mo = m;
+    swap_halves(m, mo);
+    m = fmaxf(m, mo);
+    const int e = (int)(__float_as_uint(m) >> 23);          // biased exponent (m >= 0); 255 for inf / nan
+    int se = 267 - e;                                        // largest entry -> [2^13, 2^14)
+    se = se > 253 ? 253 : se;
+    if (e == 0) se = 127;                                    // all zero (or subnormal): leave as it is
+    return PointScale{__uint_as_float((unsigned)se << 23), __uint_as_float((unsigned)(254 - se) << 23)};
+}
+// The largest of a value over the wavefront (values compared as unsigned: non-negative floats order like their
+// bit patterns), in every lane; no LDS.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));    // lanes 1,0,3,2 of each quad
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));    // lanes 2,3,0,1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));   // row half mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));   // row mirror: rows uniform
+    const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+template <int NT>
+__device__ __forceinline__ float abs_max(const f32x16 (&a)[NT], float m = 0.0f) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(fabsf(a[t][r]), fabsf(a[t][r + 1])), m);
+    return m;
+}
+
+// The weight stream of the f16 x 3 layers.  The packed layers of a kernel lie in memory in the order they are
+// used and every chunk is 16 KiB (a k-step of 8 out tiles, or two k-steps of 4), so the stream is one linear
+// run of chunks through H3_RING rotating LDS buffers: while chunk c is multiplied, chunk c+1 has landed, chunks
+// c+2 .. c+RING-2 are on their way and the copies of chunk c+RING-1 go out (in the middle of chunk c, after the
+// barrier that frees the buffer of chunk c-1).  The wait for chunk c+1 in the middle of chunk c so concerns
+// copies issued RING-2 chunks earlier: vector memory operations complete in issue order, and a shorter ring would
+// make that wait also cover the row stores of the previous k-step, whose acknowledgement takes longer than a
+// k-step.  Past the end of the stream the last chunk is copied again, so that the count of operations in flight
+// stays what the waits assume.
+constexpr int H3_RING = 4;
+constexpr int H3_LDS_FLOATS = H3_RING * H3_CHUNK_FLOATS;
+constexpr int H3_PIECES = H3_CHUNK_FLOATS / 1024;   // 1 KiB pieces per wave per chunk
+__device__ __forceinline__ const float* h3_next_chunk(const WeightStream& ws) {
+    return ws.next < ws.end ? ws.next : ws.end - H3_CHUNK_FLOATS;
+}
+__device__ __forceinline__ void h3_copy_chunk(WeightStream& ws, int buf) {
+    const float* src = h3_next_chunk(ws);
+#pragma unroll
+    for (int q = 0; q < H3_PIECES; ++q) ws_copy_piece(ws, src, ws.lds + buf * H3_CHUNK_FLOATS, q);
+    ws.next += H3_CHUNK_FLOATS;
+}
+// Start the stream at `first`: request its first RING-1 chunks.  ws_ready() must follow before the first dense_h3().
+__device__ __forceinline__ void h3_prime(WeightStream& ws, const float* first, const float* end) {
+    ws.next = first;
+    ws.end = end;
+#pragma unroll
+    for (int c = 0; c < H3_RING - 1; ++c) h3_copy_chunk(ws, c);
+    ws.g3 = 0;
+}
+
+// Row stores a layer issues in its k-step k (none in k-step 0, and nothing is assumed about the previous layer).
+template <bool DRAIN>
+constexpr int h3_stores(int k) { return DRAIN && k > 0 ? 2 : 0; }
+
+// acc[ot] (+)= W_tile(ot, kt) * (scale * in[kt]), the layer's weights being the next KT * OT / 4 chunks of the
+// stream.  A chunk is two groups of 12 MFMAs (4 out tiles x 3 terms): the two halves of a k-step (OT = 8) or two
+// k-steps (OT = 4); one barrier per chunk, between its groups.
+// ZERO: the accumulators start from zero (their contents on entry are ignored).
+// DRAIN: also write the input tiles (unscaled) to sv.rows0, tile t during k-steps 2t and 2t+1.
+template <int KT, int OT, bool DRAIN = false, bool ZERO = false>
+__device__ __forceinline__ void dense_h3(WeightStream& ws, const f32x16 (&in)[KT], float scale, f32x16 (&acc)[OT],
+                                         TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
+    static_assert(OT == 4 || OT == 8, "out tiles are processed four at a time, two groups per chunk");
+    constexpr int S = 2 * KT, G = OT / 4, NCH = S * G / 2;
+    constexpr int NM = 12, NSPLIT = 6, SLOTS = NM * G;   // MFMAs per group; steps of the operand split; MFMAs per k-step
+    constexpr int RMASK = H3_RING - 1;
+    static_assert((H3_RING & RMASK) == 0, "the ring is indexed with a mask");
+    f16x8 a[2][8];                   // operands of a group of 4 out tiles (tile*2 + piece), double-buffered
+    u32x4 b[3];                      // this k-step's B pieces (h, h'', l); the next one's are built in nh, nh2, nl
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};   // two row blocks on their way out
+    const f32x2 scale2 = {scale, scale};
+    u32x4 nh, nh2, nl;
+    f32x2 xs[4];
+    float sr0[4], sr1[4];
+    // The split of the next k-step in six steps of four independent instructions, one step every few MFMAs: an
+    // instruction issued right behind the one it depends on waits ~9 clocks with the MFMA behind it.
+    auto split_chunk = [&](auto cs, auto ck) {
+        constexpr int s = decltype(cs)::value, k = decltype(ck)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (k == 0) xs[i] = f32x2{in[s / 2][8 * (s % 2) + 2 * i], in[s / 2][8 * (s % 2) + 2 * i + 1]} * scale2;
+            else if constexpr (k == 1) nh[i] = cvt_pk_f16(xs[i][0], xs[i][1]);
+            else if constexpr (k == 2) sr0[i] = sub_f16<0>(xs[i][0], nh[i]);
+            else if constexpr (k == 3) sr1[i] = sub_f16<1>(xs[i][1], nh[i]);
+            else if constexpr (k == 4) nl[i] = cvt_pk_f16(sr0[i], sr1[i]);
+            else nh2[i] = pk_f16_down11(nh[i]);
+        }
+    };
+    auto take_split = [&]() {
+        b[0] = nh;
+        b[1] = nh2;
+        b[2] = nl;
+    };
+    auto read_one = [&](unsigned rd, auto cg, auto ce, f16x8 (&o)[8]) {   // group 0 or 1 of the chunk at rd
+        constexpr int g = decltype(cg)::value, e = decltype(ce)::value;
+        o[e] = lds_read_h8<((4 * g + e / 2) * 2 + e % 2) * 1024>(rd);
+    };
+    auto read_group = [&](unsigned rd, auto cg, f16x8 (&o)[8]) {
+        static_for<0, 8>([&](auto ce) { read_one(rd, cg, ce, o); });
+    };
+    static_for<0, NSPLIT>([&](auto ck) { split_chunk(std::integral_constant<int, 0>{}, ck); });
+    take_split();
+    {
+        const unsigned rd0 = lds_addr(ws.lds + ws.g3 * H3_CHUNK_FLOATS) + ws.lane * 16;
+        read_group(rd0, std::integral_constant<int, 0>{}, a[0]);
+    }
+    static_for<0, S>([&](auto cs) {
+        constexpr int s = decltype(cs)::value;
+        static_for<0, G>([&](auto cg) {
+            constexpr int g = decltype(cg)::value;
+            constexpr int q = s * G + g, ch = q / 2, gg = q % 2;   // group q of the layer: half gg of its chunk ch
+            constexpr int par = q % 2;
+            const int b0 = (ws.g3 + ch) & RMASK;
+            const unsigned rd = lds_addr(ws.lds + b0 * H3_CHUNK_FLOATS) + ws.lane * 16;
+            const unsigned rd_next = lds_addr(ws.lds + ((b0 + 1) & RMASK) * H3_CHUNK_FLOATS) + ws.lane * 16;
+            f16x8(&cur)[8] = a[par];
+            f16x8(&nxt)[8] = a[par ^ 1];
+            lgkm_wait();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(cur[e]));
+            if constexpr (DRAIN) {
+                asm volatile("" : "+v"(d0));
+                asm volatile("" : "+v"(d1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* copy_src = nullptr;
+            // the 12 MFMAs of the group, smallest terms first: l' * h'', h * l, h * h
+            static_for<0, NM>([&](auto cm) {
+                constexpr int m = decltype(cm)::value, term = m / 4, o = m % 4;
+                constexpr int as = term == 0 ? 1 : 0;
+                constexpr int bs = term == 0 ? 1 : term == 1 ? 2 : 0;
+                if constexpr (ZERO && s == 0 && term == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[4 * g + o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * o + as], __builtin_bit_cast(f16x8, b[bs]), zero, 0, 0, 0);
+                } else {
+                    acc[4 * g + o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 * o + as], __builtin_bit_cast(f16x8, b[bs]), acc[4 * g + o], 0, 0, 0);
+                }
+                asm volatile("" : "+a"(acc[4 * g + o]));
+                if constexpr (m == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (gg == 1) {   // the middle of the chunk: chunk ch+1 must have landed
+                        // Vector memory operations this wave has certainly issued after the copies of chunk ch+1
+                        // (RING-2 chunks ago) may stay in flight: the copies of the chunks after it and the row
+                        // stores since, which follow their k-step's copies.  This layer's k-step 0 has no stores;
+                        // at the start of a layer only the previous layer's copies are counted.
+                        constexpr int YOUNGER = (H3_RING - 3) * H3_PIECES +
+                                                (ch == 0 ? 0 : G == 2 ? h3_stores<DRAIN>(ch - 1) + h3_stores<DRAIN>(ch)
+                                                                      : h3_stores<DRAIN>(2 * ch - 3) + h3_stores<DRAIN>(2 * ch - 2) +
+                                                                        h3_stores<DRAIN>(2 * ch - 1) + h3_stores<DRAIN>(2 * ch));
+                        ws_ready<YOUNGER>();
+                        copy_src = h3_next_chunk(ws);
+                        ws.next += H3_CHUNK_FLOATS;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // One memory request per MFMA where possible: the four waves run in step, and bursts from each of
+                // them at the same moment queue up.  The next group's eight operands first,
+                if constexpr (m >= 1 && m <= 8) {
+                    if constexpr (gg == 0) read_one(rd, std::integral_constant<int, 1>{}, std::integral_constant<int, m - 1>{}, nxt);
+                    else if constexpr (q + 1 < S * G) read_one(rd_next, std::integral_constant<int, 0>{}, std::integral_constant<int, m - 1>{}, nxt);
+                }
+                // between them the copies of chunk ch+RING-1 (after the barrier of this group),
+                if constexpr (gg == 1 && m >= 2 && m % 2 == 0 && m <= 2 * H3_PIECES)
+                    ws_copy_piece(ws, copy_src, ws.lds + ((b0 + H3_RING - 1) & RMASK) * H3_CHUNK_FLOATS, m / 2 - 1);
+                // then the two row blocks read during the previous k-step leave for memory (non-temporal: they are
+                // read again only by another kernel, after gigabytes of other traffic),
+                if constexpr (DRAIN && g == 0 && s > 0 && (m == 9 || m == 10)) {
+                    constexpr int t = (s - 1) / 2, k0 = 2 * ((s - 1) % 2);
+                    if constexpr (m == 9) __builtin_nontemporal_store(d0, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * k0) * sv.ld + 32 * t));
+                    else __builtin_nontemporal_store(d1, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * (k0 + 1)) * sv.ld + 32 * t));
+                }
+                // an input tile goes into the transposition buffer and two of its row blocks come back out
+                if constexpr (DRAIN && g == 0 && s % 2 == 0 && m >= 7 && m <= 10) {
+                    constexpr int qq = m - 7;
+                    lds_write4<32 * qq>(sv.tb.wr, f32x4{in[s / 2][4 * qq], in[s / 2][4 * qq + 1], in[s / 2][4 * qq + 2], in[s / 2][4 * qq + 3]});
+                }
+                if constexpr (DRAIN && g == G - 1 && m == 11) {
+                    constexpr int k0 = 2 * (s % 2);
+                    d0 = lds_read4<8 * k0 * TILE_LD * 4>(sv.tb.rd);
+                    d1 = lds_read4<8 * (k0 + 1) * TILE_LD * 4>(sv.tb.rd);
+                }
+                if constexpr (s + 1 >= S) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s + 1 < S) {
+                    constexpr int slot = NM * g + m;
+                    static_for<(slot * NSPLIT + SLOTS - 1) / SLOTS, ((slot + 1) * NSPLIT + SLOTS - 1) / SLOTS>(
+                        [&](auto ck) { split_chunk(std::integral_constant<int, s + 1>{}, ck); });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (s + 1 < S) take_split();
+    });
+    if constexpr (DRAIN) {   // the last two row blocks
+        lgkm_wait();
+        asm volatile("" : "+v"(d0));
+        asm volatile("" : "+v"(d1));
+        constexpr int t = (S - 1) / 2;
+        __builtin_nontemporal_store(d0, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)16 * sv.ld + 32 * t));
+        __builtin_nontemporal_store(d1, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)24 * sv.ld + 32 * t));
+    }
+    ws.g3 = (ws.g3 + NCH) & RMASK;
+}
+
+// bf16 x 3 splits (v = h + m + l, 8 bits each) of the weight-gradient kernels that split per wave
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // {bf16(a), bf16(b)} rounded to nearest even, a in the low half
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     unsigned r;
@@ -211,192 +465,16 @@ __device__ __forceinline__ bf16x8 lds_read_bf8(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF_BYTES));
     return r;
 }
-// The weight stream of the bf16 x 6 layers.  The packed layers of a kernel lie in memory in the order they are
-// used and every chunk is 24 KiB (a k-step of 8 out tiles, or two k-steps of 4), so the stream is one linear
-// run of chunks through four rotating LDS buffers: while chunk c is multiplied, chunk c+1 has landed, chunk
-// c+2 is on its way and the copies of chunk c+3 go out (in the middle of chunk c, after the barrier that frees
-// the buffer of chunk c-1).  The wait for chunk c+1 in the middle of chunk c so concerns copies issued two
-// chunks earlier: vector memory operations complete in issue order, and with a ring of three that wait also
-// covered the row stores of the previous k-step, whose acknowledgement takes longer than a k-step.
-// Past the end of the stream the last chunk is copied again, so that the count of operations in flight
-// stays what the waits assume.
-constexpr int X6_RING = 4;
-constexpr int X6_LDS_FLOATS = X6_RING * X6_CHUNK_FLOATS;
-constexpr int X6_PIECES = X6_CHUNK_FLOATS / 1024;   // 1 KiB pieces per wave per chunk
-__device__ __forceinline__ const float* x6_next_chunk(const WeightStream& ws) {
-    return ws.next < ws.end ? ws.next : ws.end - X6_CHUNK_FLOATS;
-}
-__device__ __forceinline__ void x6_copy_chunk(WeightStream& ws, int buf) {
-    const float* src = x6_next_chunk(ws);
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
 #pragma unroll
-    for (int q = 0; q < X6_PIECES; ++q) ws_copy_piece(ws, src, ws.lds + buf * X6_CHUNK_FLOATS, q);
-    ws.next += X6_CHUNK_FLOATS;
-}
-// Start the stream at `first`: request its first three chunks.  ws_ready() must follow before the first dense_x6().
-__device__ __forceinline__ void x6_prime(WeightStream& ws, const float* first, const float* end) {
-    ws.next = first;
-    ws.end = end;
-    x6_copy_chunk(ws, 0);
-    x6_copy_chunk(ws, 1);
-    x6_copy_chunk(ws, 2);
-    ws.g3 = 0;
-}
-
-// Row stores a layer issues in its k-step k (none in k-step 0, and nothing is assumed about the previous layer).
-template <bool DRAIN>
-constexpr int x6_stores(int k) { return DRAIN && k > 0 ? 2 : 0; }
-
-// acc[ot] += W_tile(ot, kt) * in[kt], the layer's weights being the next KT * OT / 4 chunks of the stream.
-// A chunk is two groups of 24 MFMAs (4 out tiles x 6 terms): the two halves of a k-step (OT = 8) or two
-// k-steps (OT = 4); one barrier per chunk, between its groups.
-// DRAIN: also write the input tiles to sv.rows0, tile t during k-steps 2t and 2t+1.
-template <int KT, int OT, bool DRAIN = false>
-__device__ __forceinline__ void dense_x6(WeightStream& ws, const f32x16 (&in)[KT], f32x16 (&acc)[OT],
-                                         TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
-    static_assert(OT == 4 || OT == 8, "out tiles are processed four at a time, two groups per chunk");
-    constexpr int S = 2 * KT, G = OT / 4, NCH = S * G / 2;
-    bf16x8 a[2][12];                 // operands of a group of 4 out tiles (tile*3 + split), double-buffered
-    bf16x8 b[3];                     // this k-step's B splits (h, m, l); the next one's are built in nh, nm, nl
-    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};   // two row blocks on their way out
-    auto split_step = [&](auto cs, bf16x8 (&o)[3]) {
-        constexpr int s = decltype(cs)::value;
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = in[s / 2][8 * (s % 2) + i];
-        split3(v, o[0], o[1], o[2]);
-    };
-    // The same split for the next k-step in eleven chunks of four independent instructions, one chunk every few
-    // MFMAs: an instruction issued right behind the one it depends on waits ~9 clocks with the MFMA behind it.
-    u32x4 nh, nm, nl;
-    float sr0[4], sr1[4], sf0[4], sf1[4];
-    auto split_chunk = [&](auto cs, auto ck) {
-        constexpr int s = decltype(cs)::value, k = decltype(ck)::value;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float x0 = in[s / 2][8 * (s % 2) + 2 * i], x1 = in[s / 2][8 * (s % 2) + 2 * i + 1];
-            if constexpr (k == 0) nh[i] = cvt_pk_bf16(x0, x1);
-            else if constexpr (k == 1) sf0[i] = __uint_as_float(nh[i] << 16);
-            else if constexpr (k == 2) sf1[i] = __uint_as_float(nh[i] & 0xffff0000u);
-            else if constexpr (k == 3) sr0[i] = x0 - sf0[i];
-            else if constexpr (k == 4) sr1[i] = x1 - sf1[i];
-            else if constexpr (k == 5) nm[i] = cvt_pk_bf16(sr0[i], sr1[i]);
-            else if constexpr (k == 6) sf0[i] = __uint_as_float(nm[i] << 16);
-            else if constexpr (k == 7) sf1[i] = __uint_as_float(nm[i] & 0xffff0000u);
-            else if constexpr (k == 8) sr0[i] = sr0[i] - sf0[i];
-            else if constexpr (k == 9) sr1[i] = sr1[i] - sf1[i];
-            else nl[i] = cvt_pk_bf16(sr0[i], sr1[i]);
-        }
-    };
-    auto read_one = [&](unsigned rd, auto cg, auto ce, bf16x8 (&o)[12]) {   // group 0 or 1 of the chunk at rd
-        constexpr int g = decltype(cg)::value, e = decltype(ce)::value;
-        o[e] = lds_read_bf8<((4 * g + e / 3) * 3 + e % 3) * 1024>(rd);
-    };
-    auto read_group = [&](unsigned rd, auto cg, bf16x8 (&o)[12]) {
-        static_for<0, 12>([&](auto ce) { read_one(rd, cg, ce, o); });
-    };
-    split_step(std::integral_constant<int, 0>{}, b);
-    {
-        const unsigned rd0 = lds_addr(ws.lds + ws.g3 * X6_CHUNK_FLOATS) + ws.lane * 16;
-        read_group(rd0, std::integral_constant<int, 0>{}, a[0]);
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 hh = (__bf16)v[i];
+        const float r1 = v[i] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[i] = hh;
+        m[i] = mm;
+        l[i] = (__bf16)(r1 - (float)mm);
     }
-    static_for<0, S>([&](auto cs) {
-        constexpr int s = decltype(cs)::value;
-        static_for<0, G>([&](auto cg) {
-            constexpr int g = decltype(cg)::value;
-            constexpr int q = s * G + g, ch = q / 2, gg = q % 2;   // group q of the layer: half gg of its chunk ch
-            constexpr int par = q % 2;
-            const int b0 = (ws.g3 + ch) & 3;
-            const unsigned rd = lds_addr(ws.lds + b0 * X6_CHUNK_FLOATS) + ws.lane * 16;
-            const unsigned rd_next = lds_addr(ws.lds + ((b0 + 1) & 3) * X6_CHUNK_FLOATS) + ws.lane * 16;
-            bf16x8(&cur)[12] = a[par];
-            bf16x8(&nxt)[12] = a[par ^ 1];
-            lgkm_wait();
-#pragma unroll
-            for (int e = 0; e < 12; ++e) asm volatile("" : "+v"(cur[e]));
-            if constexpr (DRAIN) {
-                asm volatile("" : "+v"(d0));
-                asm volatile("" : "+v"(d1));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[4 * g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[2], b[0], acc[4 * g], 0, 0, 0);   // l * h of tile 0
-            asm volatile("" : "+a"(acc[4 * g]));
-            if constexpr (s + 1 < S) {
-                static_for<(24 * g * 11 + 24 * G - 1) / (24 * G), ((24 * g + 1) * 11 + 24 * G - 1) / (24 * G)>(
-                    [&](auto ck) { split_chunk(std::integral_constant<int, s + 1>{}, ck); });
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float* copy_src = nullptr;
-            if constexpr (gg == 1) {   // the middle of the chunk: chunk ch+1 must have landed
-                // Vector memory operations this wave has certainly issued after the copies of chunk ch+1 (two
-                // chunks ago) may stay in flight: the copies of chunk ch+2 and the row stores since, which follow
-                // their k-step's copies (MFMAs 13 and 15).  This layer's k-step 0 has no stores; at the start of a
-                // layer only the previous layer's copies are counted.
-                constexpr int YOUNGER = X6_PIECES + (ch == 0 ? 0 : G == 2 ? x6_stores<DRAIN>(ch - 1) + x6_stores<DRAIN>(ch)
-                                                                   : x6_stores<DRAIN>(2 * ch - 3) + x6_stores<DRAIN>(2 * ch - 2) +
-                                                                     x6_stores<DRAIN>(2 * ch - 1) + x6_stores<DRAIN>(2 * ch));
-                ws_ready<YOUNGER>();
-                copy_src = x6_next_chunk(ws);
-                ws.next += X6_CHUNK_FLOATS;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // the other 23 MFMAs of the group, smallest terms first: l*h, h*l, m*m, m*h, h*m, h*h
-            static_for<1, 24>([&](auto cm) {
-                constexpr int m = decltype(cm)::value, term = m / 4, o = m % 4;
-                constexpr int as = term == 0 ? 2 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 1 : 0;
-                constexpr int bs = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
-                acc[4 * g + o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[3 * o + as], b[bs], acc[4 * g + o], 0, 0, 0);
-                asm volatile("" : "+a"(acc[4 * g + o]));
-                // One memory request per MFMA: the four waves run in step, and bursts from each of them at the same
-                // moment queue up.  The next group's twelve operands first,
-                if constexpr (m <= 12) {
-                    if constexpr (gg == 0) read_one(rd, std::integral_constant<int, 1>{}, std::integral_constant<int, m - 1>{}, nxt);
-                    else if constexpr (q + 1 < S * G) read_one(rd_next, std::integral_constant<int, 0>{}, std::integral_constant<int, m - 1>{}, nxt);
-                }
-                // between them the copies of chunk ch+3 (after the barrier of this group),
-                if constexpr (gg == 1 && m % 2 == 0 && m <= 12)
-                    ws_copy_piece(ws, copy_src, ws.lds + ((b0 + 3) & 3) * X6_CHUNK_FLOATS, m / 2 - 1);
-                // then the two row blocks read during the previous k-step leave for memory (non-temporal: they are
-                // read again only by another kernel, after gigabytes of other traffic),
-                if constexpr (DRAIN && g == 0 && s > 0 && (m == 13 || m == 15)) {
-                    constexpr int t = (s - 1) / 2, k0 = 2 * ((s - 1) % 2);
-                    if constexpr (m == 13) __builtin_nontemporal_store(d0, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * k0) * sv.ld + 32 * t));
-                    else __builtin_nontemporal_store(d1, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)(8 * (k0 + 1)) * sv.ld + 32 * t));
-                }
-                // an input tile goes into the transposition buffer and two of its row blocks come back out
-                if constexpr (DRAIN && g == 0 && s % 2 == 0 && m >= 13 && m <= 16) {
-                    constexpr int qq = m - 13;
-                    lds_write4<32 * qq>(sv.tb.wr, f32x4{in[s / 2][4 * qq], in[s / 2][4 * qq + 1], in[s / 2][4 * qq + 2], in[s / 2][4 * qq + 3]});
-                }
-                if constexpr (DRAIN && g == G - 1 && (m == 17 || m == 18)) {
-                    constexpr int k0 = 2 * (s % 2);
-                    if constexpr (m == 17) d0 = lds_read4<8 * k0 * TILE_LD * 4>(sv.tb.rd);
-                    else d1 = lds_read4<8 * (k0 + 1) * TILE_LD * 4>(sv.tb.rd);
-                }
-                if constexpr (s + 1 >= S) __builtin_amdgcn_sched_barrier(0);
-                if constexpr (s + 1 < S) {
-                    constexpr int slot = 24 * g + m;
-                    static_for<(slot * 11 + 24 * G - 1) / (24 * G), ((slot + 1) * 11 + 24 * G - 1) / (24 * G)>(
-                        [&](auto ck) { split_chunk(std::integral_constant<int, s + 1>{}, ck); });
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if constexpr (s + 1 < S) {
-            b[0] = __builtin_bit_cast(bf16x8, nh);
-            b[1] = __builtin_bit_cast(bf16x8, nm);
-            b[2] = __builtin_bit_cast(bf16x8, nl);
-        }
-    });
-    if constexpr (DRAIN) {   // the last two row blocks
-        lgkm_wait();
-        asm volatile("" : "+v"(d0));
-        asm volatile("" : "+v"(d1));
-        constexpr int t = (S - 1) / 2;
-        __builtin_nontemporal_store(d0, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)16 * sv.ld + 32 * t));
-        __builtin_nontemporal_store(d1, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)24 * sv.ld + 32 * t));
-    }
-    ws.g3 = (ws.g3 + NCH) & 3;
 }
 
 // dot_rows() below with the vector in LDS (byte address v_lds): a vector-memory load at that point would wait
@@ -424,7 +502,9 @@ __device__ __forceinline__ float dot_rows_lds(const f32x16 (&a)[NT], unsigned v_
                 for (int e = 0; e < 4; ++e) s = fmaf(a[t0 + t][4 * q + e], w[t][q][e], s);
             }
     });
-    return s + __shfl_xor(s, 32, 64);
+    float so = s;
+    swap_halves(s, so);
+    return s + so;
 }
 
 // acc tiles <- per-neuron vector v[32*t + rowmap(r,h)] (bias as the initial accumulator).
@@ -441,6 +521,41 @@ __device__ __forceinline__ void fill_rows(f32x16 (&acc)[NT], const float* __rest
             acc[t][4 * q + 3] = b.w;
         }
     }
+}
+
+// Epilogue of a dense_h3 layer: a = a * inv + bias[32t + rowmap(r, h)] (bias in LDS at byte address bias_lds;
+// asm reads, see the note on LDS accesses above), optionally through a ReLU.
+template <int NT, bool RELU>
+__device__ __forceinline__ void finish_tiles(f32x16 (&a)[NT], float inv, unsigned bias_lds, int h) {
+    const unsigned a0 = bias_lds + 16 * h;
+    static_for<0, NT / 2>([&](auto cpair) {
+        constexpr int t0 = 2 * decltype(cpair)::value;
+        f32x4 bv[2][4];
+        static_for<0, 2>([&](auto ct) {
+            static_for<0, 4>([&](auto cq) {
+                bv[ct][cq] = lds_read4<(32 * (t0 + decltype(ct)::value) + 8 * decltype(cq)::value) * 4>(a0);
+            });
+        });
+        lgkm_wait();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                asm volatile("" : "+v"(bv[t][q]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaf(a[t0 + t][4 * q + e], inv, bv[t][q][e]);
+                    a[t0 + t][4 * q + e] = RELU ? fmaxf(v, 0.0f) : v;
+                }
+            }
+    });
+}
+template <int NT>
+__device__ __forceinline__ void scale_tiles(f32x16 (&a)[NT], float inv) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[t][r] *= inv;
 }
 
 template <int NT>
@@ -557,7 +672,7 @@ struct PackJob {
     int mode;          // 0: forward pack, 1: backward (transposed) pack, 2: plain copy of `count` floats, 3: zero fill
     int hash_perm;     // hash-grid first layer: tile position rowmap(r,h) stands for feature 16h + r
     int KT, OT;        // tiles of the contraction / output dimension of the packed operand
-    int x6;            // write the operand as three bf16 splits in the dense_x6 order (1.5x the size)
+    int h3;            // write the operand as two f16 pieces in the dense_h3 order (the same size)
     int seg_eff[2], seg_len[2], seg_src[2];  // forward: effective input k in [eff, eff+len) reads column src + (k-eff)
     int col_begin, col_count;                 // backward: output m in [m_first, m_first+col_count) reads column col_begin + (m - m_first)
     int m_first;

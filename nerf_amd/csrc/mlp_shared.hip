@@ -43,17 +43,15 @@ __global__ void pack_kernel(PackJobs jobs, float* __restrict__ packed) {
                 }
             }
         }
-        if (jb.x6 && jb.mode < 2) {
-            // bf16 x 3 form for dense_x6: [k-step = 2*kt + r/8][out tile][split][lane][r%8]
+        if (jb.h3 && jb.mode < 2) {
+            // two f16 pieces for dense_h3: [k-step = 2*kt + r/8][out tile][h, l'][lane][r%8], l' = 2^11 (v - h)
             const int ot = idx % jb.OT, lane = (idx / jb.OT) % 64, r = (idx / (jb.OT * 64)) % 16, kt = idx / (jb.OT * 64 * 16);
-            const float in8[8] = {v, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            bf16x8 h, m, l;
-            split3(in8, h, m, l);
-            __bf16* out = reinterpret_cast<__bf16*>(packed + jb.dst);
-            const size_t base = ((size_t)((2 * kt + (r >> 3)) * jb.OT + ot) * 3 * 64 + lane) * 8 + (r & 7);
-            out[base] = h[0];
-            out[base + 64 * 8] = m[0];
-            out[base + 2 * 64 * 8] = l[0];
+            const _Float16 hh = (_Float16)v;
+            const _Float16 ll = (_Float16)((v - (float)hh) * 2048.0f);
+            _Float16* out = reinterpret_cast<_Float16*>(packed + jb.dst);
+            const size_t base = ((size_t)((2 * kt + (r >> 3)) * jb.OT + ot) * 2 * 64 + lane) * 8 + (r & 7);
+            out[base] = hh;
+            out[base + 64 * 8] = ll;
         } else {
             packed[jb.dst + idx] = v;
         }

@@ -2,9 +2,9 @@
 // FastMLPNeRF.forward, src/models/FastMLPNeRF.py:47-70).
 //
 // Forward: one wavefront per 32 points; positional encodings are computed in
-// registers, every layer is a chain of bf16 x 6 MFMAs (fp32-accurate) whose accumulators become
-// the next layer's B operands (see mlp_common.h), weights stream from the
-// packed buffer (L2-resident, 7 MB) through LDS, copied once per workgroup.  For training the activations are written
+// registers, every layer is a chain of split-f16 MFMAs (three per product, fp32-accurate) whose accumulators
+// become the next layer's B operands (see mlp_common.h), weights stream from the
+// packed buffer (L2-resident, 5 MB) through LDS, copied once per workgroup.  For training the activations are written
 // row-major for the weight-gradient GEMMs plus one ReLU bit per neuron for the
 // backward-data kernel.
 // Backward: (1) a fused backward-data chain in the same register layout that
@@ -14,7 +14,7 @@
 
 namespace nerf {
 namespace vp {  // float offsets into the packed buffer
-constexpr int wfloats(int KT, int OT) { return x6_layer_floats(KT, OT); }
+constexpr int wfloats(int KT, int OT) { return h3_layer_floats(KT, OT); }
 constexpr int T88 = wfloats(8, 8);
 constexpr int F_L0 = 0;                     // 63(64) -> 256
 constexpr int F_L1 = F_L0 + wfloats(2, 8);  // layers 1,2,3
@@ -34,9 +34,9 @@ constexpr int S_WS = S_B1 + 128;
 constexpr int S_BS = S_WS + 256;
 constexpr int S_W2 = S_BS + 4;
 constexpr int S_B2 = S_W2 + 3 * 128;
-constexpr int HEAD_FLOATS = 3 * 256;         // the head weights from S_WS on, padded to whole 1 KiB pieces: the forward
-constexpr int TOTAL = S_WS + HEAD_FLOATS;    // kernel keeps a copy in LDS
-static_assert(S_B2 + 4 <= TOTAL, "head-weight block");
+constexpr int CONST_FLOATS = 13 * 256;       // the biases and head weights from S_BIAS on, padded to whole 1 KiB pieces:
+constexpr int TOTAL = S_BIAS + CONST_FLOATS; // the kernels keep a copy in LDS
+static_assert(S_B2 + 4 <= TOTAL, "constant block");
 }  // namespace vp
 
 namespace vw {  // workspace layout, floats per point (multiply by P32 for the section offset)
@@ -52,7 +52,8 @@ constexpr int DY = 0;           // 8 x [P32][256]
 constexpr int DFEAT = 8 * 256;
 constexpr int DYR = DFEAT + 256;   // [P32][128]
 constexpr int DOUT4 = DYR + 128;   // [P32][4] = (d sigma_pre, d rgb_pre[3])
-constexpr int PER_POINT2 = DOUT4 + 4;
+constexpr int AMAX = DOUT4 + 4;    // the first 16 words: largest |entry| of each gradient matrix (float bits)
+constexpr int PER_POINT2 = AMAX + 4;
 }  // namespace vw
 
 struct TileIdx {
@@ -78,15 +79,35 @@ __device__ __forceinline__ void tile_index(long long P, TileIdx& ix) {
     ix.P32 = (P + 31) / 32 * 32;
 }
 
-// One dense layer through the weight stream (bf16 x 6 MFMAs); the stream knows which layer comes next.
-template <int KT, int OT, bool DRAIN = false>
-__device__ __forceinline__ void dense_layer(WeightStream& ws, const f32x16 (&in)[KT], f32x16 (&acc)[OT],
+// One dense layer through the weight stream (split-f16 MFMAs); the stream knows which layer comes next.
+template <int KT, int OT, bool DRAIN = false, bool ZERO = false>
+__device__ __forceinline__ void dense_layer(WeightStream& ws, const f32x16 (&in)[KT], float scale, f32x16 (&acc)[OT],
                                             TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
-    dense_x6<KT, OT, DRAIN>(ws, in, acc, sv);
+    dense_h3<KT, OT, DRAIN, ZERO>(ws, in, scale, acc, sv);
 }
-constexpr int STREAM_LDS_FLOATS = X6_LDS_FLOATS;
-constexpr int HEAD_LDS_OFF = STREAM_LDS_FLOATS + 4 * TILE_LDS_FLOATS;
-constexpr int KERNEL_LDS_FLOATS = HEAD_LDS_OFF + vp::HEAD_FLOATS;
+constexpr int STREAM_LDS_FLOATS = H3_LDS_FLOATS;
+constexpr int CONST_LDS_OFF = STREAM_LDS_FLOATS + 4 * TILE_LDS_FLOATS;
+constexpr int KERNEL_LDS_FLOATS = CONST_LDS_OFF + vp::CONST_FLOATS;
+constexpr int MASK_LDS_OFF = KERNEL_LDS_FLOATS;                       // backward: the ReLU bits of the wave's tile,
+constexpr int BWD_LDS_FLOATS = MASK_LDS_OFF + 4 * 9 * 256;            // 9 layers x 1 KiB per wave
+static_assert(BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS of a workgroup");
+
+// The biases and head weights go to LDS with the first chunks of the weight stream; complete after ws_ready().
+// Returns the LDS byte address of packed offset S_BIAS.
+__device__ __forceinline__ unsigned copy_consts(float* lds, const float* __restrict__ pk, int wave, int lane) {
+    const WeightStream w{lds, 0, wave, lane};
+#pragma unroll
+    for (int q = 0; q < (vp::CONST_FLOATS / 256 + 3) / 4; ++q)
+        if (4 * q + wave < vp::CONST_FLOATS / 256) ws_copy_piece(w, pk + vp::S_BIAS, lds + CONST_LDS_OFF, q);
+    return lds_addr(lds + CONST_LDS_OFF);
+}
+__device__ __forceinline__ float lds_read1(unsigned addr) {
+    float r;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(addr));
+    lgkm_wait();
+    asm volatile("" : "+v"(r));
+    return r;
+}
 
 template <bool SAVE>
 __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restrict__ x, const float* __restrict__ dirs,
@@ -100,90 +121,115 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     WeightStream wst{lds, 0, ix.wave, lane};
     const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
     // the weight stream runs through the packed layers in the order they are used
-    // the head weights (density row, rgb rows) go to LDS with the first chunks; complete after ws_ready()
-    if (ix.wave < vp::HEAD_FLOATS / 256) ws_copy_piece(WeightStream{lds, 0, ix.wave, lane}, pk + vp::S_WS, lds + HEAD_LDS_OFF, 0);
-    const unsigned heads = lds_addr(lds + HEAD_LDS_OFF);
-    x6_prime(wst, pk + vp::F_L0, pk + vp::B_RGB0);
+    const unsigned consts = copy_consts(lds, pk, ix.wave, lane);
+    auto const_at = [&](int packed_off) { return consts + 4 * (packed_off - vp::S_BIAS); };
+    h3_prime(wst, pk + vp::F_L0, pk + vp::B_RGB0);
     const float x0 = x[3 * ix.lp], x1 = x[3 * ix.lp + 1], x2 = x[3 * ix.lp + 2];
+    const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
+    const float dir0 = dirs[3 * dr], dir1 = dirs[3 * dr + 1], dir2 = dirs[3 * dr + 2];
     uint4* mask_out = SAVE ? reinterpret_cast<uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane : nullptr;
 
     f32x16 xe[2];
     pe_tiles<2, 10>(xe, x0, x1, x2, h);
+    const float mx = abs_max<2>(xe);
     ws_ready();
 
     f32x16 hc[8], acc[8];
     // Training: the activations of layer l are the input tiles of layer l+1, which writes
     // them out row by row underneath its MFMAs (see TileSave).
     auto rows_of = [&](int section) { return tile_save(tb, ws + ix.P32 * section + ix.tile * 32 * 256); };
-    auto finish_layer = [&](int l) {
-        relu_tiles<8>(acc);
+    float mh = 0.0f;   // largest |activation| of this lane's half of the current layer
+    auto finish_layer = [&](int l, float inv) {
+        finish_tiles<8, true>(acc, inv, const_at(vp::S_BIAS + 256 * l), h);
 #pragma unroll
         for (int t = 0; t < 8; ++t) hc[t] = acc[t];
         if (SAVE) mask_out[l * 64] = relu_bits<8>(hc);
+        mh = abs_max<8>(hc);
     };
     // layer 0
-    fill_rows<8>(acc, pk + vp::S_BIAS, h);
-    dense_layer<2, 8, SAVE>(wst, xe, acc,
-                             tile_save(tb, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64));
-    finish_layer(0);
+    PointScale sc = point_scale(mx);
+    dense_layer<2, 8, SAVE, true>(wst, xe, sc.s, acc, tile_save(tb, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64));
+    finish_layer(0, sc.inv);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
-        fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense_layer<8, 8, SAVE>(wst, hc, acc, rows_of(vw::H + 256 * (l - 1)));
-        finish_layer(l);
+        sc = point_scale(mh);
+        dense_layer<8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1)));
+        finish_layer(l, sc.inv);
     }
-    // skip connection: the layer-4 input is [x_enc | h] (either column order, see the packing)
-    fill_rows<8>(acc, pk + vp::S_BIAS + 256 * 4, h);
-    dense_layer<2, 8>(wst, xe, acc);
-    dense_layer<8, 8, SAVE>(wst, hc, acc, rows_of(vw::H + 256 * 3));
-    finish_layer(4);
+    // skip connection: the layer-4 input is [x_enc | h] (either column order, see the packing), one scale for both
+    sc = point_scale(fmaxf(mx, mh));
+    dense_layer<2, 8, false, true>(wst, xe, sc.s, acc);
+    dense_layer<8, 8, SAVE>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 3));
+    finish_layer(4, sc.inv);
 #pragma unroll 1
     for (int l = 5; l < 8; ++l) {
-        fill_rows<8>(acc, pk + vp::S_BIAS + 256 * l, h);
-        dense_layer<8, 8, SAVE>(wst, hc, acc, rows_of(vw::H + 256 * (l - 1)));
-        finish_layer(l);
+        sc = point_scale(mh);
+        dense_layer<8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1)));
+        finish_layer(l, sc.inv);
     }
     // density head: softplus(w.h + b)   (NeRF.py:90)
-    const float sp = dot_rows_lds<8>(hc, heads, h) + pk[vp::S_BS];
+    const float sp = dot_rows_lds<8>(hc, const_at(vp::S_WS), h) + lds_read1(const_at(vp::S_BS));
     if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(sp);
     // feature layer (no activation)      (NeRF.py:95)
-    fill_rows<8>(acc, pk + vp::S_BF, h);
-    dense_layer<8, 8, SAVE>(wst, hc, acc, rows_of(vw::H + 256 * 7));
+    sc = point_scale(mh);
+    dense_layer<8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 7));
+    finish_tiles<8, false>(acc, sc.inv, const_at(vp::S_BF), h);
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
-    const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
-    pe_tiles<1, 4>(de, dirs[3 * dr], dirs[3 * dr + 1], dirs[3 * dr + 2], h);
+    pe_tiles<1, 4>(de, dir0, dir1, dir2, h);
+    sc = point_scale(abs_max<1>(de, abs_max<8>(acc)));
     f32x16 hr[4];
-    fill_rows<4>(hr, pk + vp::S_B1, h);
-    dense_layer<8, 4, SAVE>(wst, acc, hr, rows_of(vw::FEAT));
-    dense_layer<1, 4, SAVE>(wst, de, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
-    relu_tiles<4>(hr);
+    dense_layer<8, 4, SAVE, true>(wst, acc, sc.s, hr, rows_of(vw::FEAT));
+    dense_layer<1, 4, SAVE>(wst, de, sc.s, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
+    finish_tiles<4, true>(hr, sc.inv, const_at(vp::S_B1), h);
     if (SAVE) {
         save_tiles<4>(tb, ws + ix.P32 * vw::HR + ix.tile * 32 * 128, 128, hr);
         mask_out[8 * 64] = relu_bits<4>(hr);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float v = dot_rows_lds<4>(hr, heads + 4 * (vp::S_W2 - vp::S_WS + 128 * c), h) + pk[vp::S_B2 + c];
+        const float v = dot_rows_lds<4>(hr, const_at(vp::S_W2 + 128 * c), h) + lds_read1(const_at(vp::S_B2 + c));
         if (ix.valid && h == 0) rgb[3 * ix.gp + c] = sigmoid_f(v);
     }
 }
 
-// Backward-data chain.  Emits d(pre-activation) of every layer row-major into ws2.
+// Backward-data chain.  Emits d(pre-activation) of every layer row-major into ws2, and the largest |entry| of
+// each of those matrices (as the bit pattern of a non-negative float) into amax[0..9]: layer 0..7, feature
+// layer, colour hidden layer.  The weight-gradient kernel scales its operands by them.
 __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __restrict__ d_rgb,
                                                                const float* __restrict__ d_sigma, long long P,
                                                                const float* __restrict__ pk,
                                                                const float* __restrict__ rgb,
                                                                const float* __restrict__ sigma,
-                                                               const float* __restrict__ ws, float* __restrict__ ws2) {
-    __shared__ __attribute__((aligned(16))) float lds[KERNEL_LDS_FLOATS];
+                                                               const float* __restrict__ ws, float* __restrict__ ws2,
+                                                               unsigned* __restrict__ amax) {
+    __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
     TileIdx ix;
     tile_index(P, ix);
     const int lane = ix.lane, h = ix.h;
     WeightStream wst{lds, 0, ix.wave, lane};
     const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
-    x6_prime(wst, pk + vp::B_RGB0, pk + vp::S_BIAS);
-    const uint4* mask_in = reinterpret_cast<const uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane;
+    const unsigned consts = copy_consts(lds, pk, ix.wave, lane);
+    auto const_at = [&](int packed_off) { return consts + 4 * (packed_off - vp::S_BIAS); };
+    // the ReLU bits of this wave's tile, [layer][lane] 16 bytes each, also through LDS (a load from memory in the
+    // middle of the chain would wait for every weight copy in flight)
+    float* mask_lds = lds + MASK_LDS_OFF + ix.wave * 9 * 256;
+    {
+        const uint4* mask_in = reinterpret_cast<const uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane;
+#pragma unroll
+        for (int l = 0; l < 9; ++l)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mask_in + l * 64),
+                                             (__attribute__((address_space(3))) void*)(mask_lds + l * 256), 16, 0, 0);
+    }
+    const unsigned mask_rd = lds_addr(mask_lds) + lane * 16;
+    auto bits_of = [&](int l) {
+        const f32x4 v = lds_read4<0>(mask_rd + l * 1024);
+        lgkm_wait();
+        f32x4 w = v;
+        asm volatile("" : "+v"(w));
+        return make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
+    };
+    h3_prime(wst, pk + vp::B_RGB0, pk + vp::S_BIAS);
     float dpre[3], dps = 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -192,57 +238,92 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
     }
     if (ix.valid) dps = d_sigma[ix.lp] * (1.0f - expf(-sigma[ix.lp]));          // softplus' = 1 - exp(-softplus)
     if (h == 0) *reinterpret_cast<float4*>(ws2 + ix.P32 * vw::DOUT4 + ix.gp * 4) = make_float4(dps, dpre[0], dpre[1], dpre[2]);
+    ws_ready();
+
+    // The wave's largest |entry| of a gradient matrix joins the global maximum.  A tile beyond the last one repeats
+    // the last tile's values, which changes nothing.
+    auto publish_max = [&](float m, int slot) {
+        const unsigned wm = wave_max_u32(__float_as_uint(m));
+        if (lane == 0) atomicMax(amax + slot, wm);
+    };
 
     // d hr = W2^T d rgb_pre, masked by the ReLU of the colour hidden layer
     f32x16 dyr[4];
+    {
+        const unsigned w2 = const_at(vp::S_W2) + 16 * h;
+        static_for<0, 4>([&](auto ct) {
+            constexpr int t = decltype(ct)::value;
+            f32x4 w[3][4];
+            static_for<0, 3>([&](auto cc) {
+                static_for<0, 4>([&](auto cq) {
+                    w[cc][cq] = lds_read4<(128 * decltype(cc)::value + 32 * t + 8 * decltype(cq)::value) * 4>(w2);
+                });
+            });
+            lgkm_wait();
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = 0; e < 4; ++e) {
+                    float sum = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float4 w = *reinterpret_cast<const float4*>(pk + vp::S_W2 + 128 * c + 32 * t + 8 * q + 4 * h);
-                s.x = fmaf(w.x, dpre[c], s.x);
-                s.y = fmaf(w.y, dpre[c], s.y);
-                s.z = fmaf(w.z, dpre[c], s.z);
-                s.w = fmaf(w.w, dpre[c], s.w);
-            }
-            dyr[t][4 * q + 0] = s.x;
-            dyr[t][4 * q + 1] = s.y;
-            dyr[t][4 * q + 2] = s.z;
-            dyr[t][4 * q + 3] = s.w;
-        }
-    apply_bits<4>(dyr, mask_in[8 * 64]);
-    ws_ready();
+                    for (int c = 0; c < 3; ++c) {
+                        asm volatile("" : "+v"(w[c][q]));
+                        sum = fmaf(w[c][q][e], dpre[c], sum);
+                    }
+                    dyr[t][4 * q + e] = sum;
+                }
+        });
+    }
+    apply_bits<4>(dyr, bits_of(8));
 
     // Each 256-wide gradient tile set is the input of the next layer down, which writes it out underneath its MFMAs.
     auto rows_of = [&](int section) { return tile_save(tb, ws2 + ix.P32 * section + ix.tile * 32 * 256); };
     f32x16 a[8], b[8];
-    zero_tiles<8>(a);
-    dense_layer<4, 8, true>(wst, dyr, a,
-                             tile_save(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128));   // d feat
-    zero_tiles<8>(b);
-    dense_layer<8, 8, true>(wst, a, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
+    float m = abs_max<4>(dyr);
+    publish_max(m, 9);
+    PointScale sc = point_scale(m);
+    dense_layer<4, 8, true, true>(wst, dyr, sc.s, a,
+                                  tile_save(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128));   // d feat
+    scale_tiles<8>(a, sc.inv);
+    m = abs_max<8>(a);
+    publish_max(m, 8);
+    sc = point_scale(m);
+    dense_layer<8, 8, true, true>(wst, a, sc.s, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
+    {
+        const unsigned wsig = const_at(vp::S_WS) + 16 * h;
+        static_for<0, 2>([&](auto chalf) {                                 // ... plus the density head
+            constexpr int t0 = 4 * decltype(chalf)::value;
+            f32x4 w[4][4];
+            static_for<0, 4>([&](auto ct) {
+                static_for<0, 4>([&](auto cq) {
+                    w[ct][cq] = lds_read4<(32 * (t0 + decltype(ct)::value) + 8 * decltype(cq)::value) * 4>(wsig);
+                });
+            });
+            lgkm_wait();
 #pragma unroll
-    for (int t = 0; t < 8; ++t)                    // ... plus the density head
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 w = *reinterpret_cast<const float4*>(pk + vp::S_WS + 32 * t + 8 * q + 4 * h);
-            b[t][4 * q + 0] = fmaf(w.x, dps, b[t][4 * q + 0]);
-            b[t][4 * q + 1] = fmaf(w.y, dps, b[t][4 * q + 1]);
-            b[t][4 * q + 2] = fmaf(w.z, dps, b[t][4 * q + 2]);
-            b[t][4 * q + 3] = fmaf(w.w, dps, b[t][4 * q + 3]);
-        }
-    apply_bits<8>(b, mask_in[7 * 64]);
+                for (int q = 0; q < 4; ++q) {
+                    asm volatile("" : "+v"(w[t][q]));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        b[t0 + t][4 * q + e] = fmaf(w[t][q][e], dps, b[t0 + t][4 * q + e] * sc.inv);
+                }
+        });
+    }
+    apply_bits<8>(b, bits_of(7));
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                 // d h_{l-1} = W_l^T d y_l (h columns only at l = 4)
-        zero_tiles<8>(a);
-        dense_layer<8, 8, true>(wst, b, a, rows_of(vw::DY + l * 256));
-        apply_bits<8>(a, mask_in[(l - 1) * 64]);
+        m = abs_max<8>(b);
+        publish_max(m, l);
+        sc = point_scale(m);
+        dense_layer<8, 8, true, true>(wst, b, sc.s, a, rows_of(vw::DY + l * 256));
+        scale_tiles<8>(a, sc.inv);
+        apply_bits<8>(a, bits_of(l - 1));
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[t] = a[t];
     }
+    publish_max(abs_max<8>(b), 0);
     save_tiles<8>(tb, ws2 + ix.P32 * vw::DY + ix.tile * 32 * 256, 256, b);
 }
 
@@ -300,7 +381,7 @@ extern "C" int nerf_mlp_vanilla_pack(const float* const* params, int skip_h_firs
     J.job[n++] = pack_bwd_job(Wf, 256, 256, vp::B_FEAT, 8, 8, 0, 256);
     for (int l = 7; l >= 1; --l)
         J.job[n++] = pack_bwd_job(Wl(l), l == 4 ? 319 : 256, 256, vp::B_L7 + (7 - l) * vp::T88, 8, 8, l == 4 ? h_col : 0, 256);
-    for (int i = 0; i < n; ++i) J.job[i].x6 = 1;   // every matrix above feeds a dense layer
+    for (int i = 0; i < n; ++i) J.job[i].h3 = 1;   // every matrix above feeds a dense layer
     for (int l = 0; l < 8; ++l) J.job[n++] = pack_copy_job(bl(l), vp::S_BIAS + 256 * l, 256);
     J.job[n++] = pack_copy_job(bf, vp::S_BF, 256);
     J.job[n++] = pack_copy_job(b1, vp::S_B1, 128);
@@ -337,8 +418,10 @@ extern "C" int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, in
     NERF_REQUIRE(P >= 0, "nerf_mlp_vanilla_bwd: P=%lld", (long long)P);
     hipStream_t st = (hipStream_t)stream;
     if (phases & 1) {
+        unsigned* amax = reinterpret_cast<unsigned*>(ws2 + (size_t)((P + 31) / 32 * 32) * vw::AMAX);
+        if (hipMemsetAsync(amax, 0, 16 * sizeof(unsigned), st) != hipSuccess) return fail(NERF_ELAUNCH, "nerf_mlp_vanilla_bwd: memset failed");
         hipLaunchKernelGGL(vanilla_bwd_data_kernel, dim3((unsigned)ceil_div(P, 128)), dim3(256), 0, st, d_rgb, d_sigma,
-                           (long long)P, packed, rgb, sigma, ws, ws2);
+                           (long long)P, packed, rgb, sigma, ws, ws2, amax);
         if (int rc = check_launch("nerf_mlp_vanilla_bwd(data)")) return rc;
     }
     if (!(phases & 2)) return NERF_OK;
