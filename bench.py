@@ -33,10 +33,18 @@ FLOP_FWD = 2 * 593408
 FLOP_BWD_DATA = 2 * (593408 - 63 * 256 - 63 * 256 - 27 * 128)   # no gradient into the encodings
 FLOP_WGRAD = 2 * 593408
 PEAK_F32_MATRIX_TFLOPS = 157.3
-# All three MLP kernels form an fp32 product from 6 bf16 MFMAs (operands split in three, the six
-# partial products that matter): the roofline of an fp32-equivalent FLOP is the dense bf16 peak / 6.
-PEAK_BF16_MATRIX_TFLOPS = 2500.0
-MFMA_PER_PRODUCT = 6
+# All three MLP kernels form an fp32 product from 3 f16 MFMAs (operands split in two f16 pieces, the three
+# partial products that matter): the matrix roofline of an fp32-equivalent FLOP is the dense f16 peak / 3.
+PEAK_F16_MATRIX_TFLOPS = 2500.0
+MFMA_PER_PRODUCT = 3
+PEAK_HBM_GBS = 8000.0
+# Algorithmic HBM bytes per point of the three kernels (every array read or written exactly once):
+# forward: x, rgb, sigma; the saved activations x_enc 64, d_enc 32, h0..h7 8x256, feat 256, hr 128 floats; 288 B of ReLU bits
+BYTES_FWD = 4 * (3 + 3 + 1) + 4 * (64 + 32 + 8 * 256 + 256 + 128) + 288
+# backward-data: d y0..7, d feat, d hr, 4 head gradients written; ReLU bits, d_rgb, d_sigma, rgb, sigma read
+BYTES_BWD_DATA = 4 * (8 * 256 + 256 + 128 + 4) + 288 + 4 * (3 + 1 + 3 + 1)
+# weight gradients: every saved activation and every gradient matrix read once
+BYTES_WGRAD = 4 * (8 * 256 + 256 + 128) + 4 * (64 + 32 + 8 * 256 + 256)
 
 
 def lego_pose(seed: int) -> torch.Tensor:
@@ -206,7 +214,7 @@ def gpu_main(args):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (operands split into 3 bf16 each, 6 bf16 MFMAs per product, fp32 accumulate: fp32-accurate)",
+            "dtype": "f32 (operands split into 2 f16 pieces each, 3 f16 MFMAs per product, fp32 accumulate: fp32-accurate)",
             "data": "synthetic",
             "config": {"workload": "vanilla NeRF 8x256 coarse+fine, Blender-lego-shaped 800x800 camera, "
                                    "64 coarse + 128 fine samples, %d-ray batch per GPU%s, one training step "
@@ -266,13 +274,15 @@ def kernel_roofline(model, rays, dev):
     t_bd = _time_kernel(lambda: ops.vanilla_bwd_raw(d_rgb, d_sig, packed, rgb, sigma, ws, ws2, False, grads, phases=1))
     t_wg = _time_kernel(lambda: ops.vanilla_bwd_raw(d_rgb, d_sig, packed, rgb, sigma, ws, ws2, False, grads, phases=2))
     kernels = {
-        "vanilla_fwd_kernel": (t_fwd, FLOP_FWD),
-        "vanilla_bwd_data_kernel": (t_bd, FLOP_BWD_DATA),
-        "wgrad_kernel": (t_wg, FLOP_WGRAD),
+        "vanilla_fwd_kernel": (t_fwd, FLOP_FWD, BYTES_FWD),
+        "vanilla_bwd_data_kernel": (t_bd, FLOP_BWD_DATA, BYTES_BWD_DATA),
+        "wgrad_kernel": (t_wg, FLOP_WGRAD, BYTES_WGRAD),
     }
     name = max(kernels, key=lambda k: kernels[k][0])
-    t, flop = kernels[name]
-    achieved = flop * P / t / 1e12
+    t, flop, nbytes = kernels[name]
+    tflops = flop * P / t / 1e12
+    gbs = nbytes * P / t / 1e9
+    peak_mfma = PEAK_F16_MATRIX_TFLOPS / MFMA_PER_PRODUCT
     # HBM bytes per launch of that kernel from the committed PMC passes (measured
     # offline with rocprofv3 --pmc: a counter run cannot be nested inside this one)
     traffic = None
@@ -283,13 +293,19 @@ def kernel_roofline(model, rays, dev):
             traffic = tr[name]["hbm_bytes"]
     except (OSError, ValueError, KeyError):
         traffic = None
-    peak = PEAK_BF16_MATRIX_TFLOPS / MFMA_PER_PRODUCT
-    return {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": traffic, "points_per_launch": P,
-            "note": "achieved = algorithmic (fp32-equivalent) FLOP/s; peak = 2500 TFLOP/s dense bf16 / 6 bf16 MFMAs per "
-                    "fp32 product; executed bf16 rate = 6 x achieved; the exact-f32 MFMA peak is 157.3",
-            "executed_bf16_tflops": achieved * MFMA_PER_PRODUCT,
-            "all_kernels_tflops": {k: v[1] * P / v[0] / 1e12 for k, v in kernels.items()},
+    # the kernel is bounded by whichever resource it uses the larger fraction of
+    hbm_bound = gbs / PEAK_HBM_GBS >= tflops / peak_mfma
+    per_kernel = {k: {"ms": v[0] * 1e3, "tflops": v[1] * P / v[0] / 1e12, "mfma_frac": v[1] * P / v[0] / 1e12 / peak_mfma,
+                      "gbs": v[2] * P / v[0] / 1e9, "hbm_frac": v[2] * P / v[0] / 1e9 / PEAK_HBM_GBS} for k, v in kernels.items()}
+    return {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
+            "achieved": gbs if hbm_bound else tflops, "peak": PEAK_HBM_GBS if hbm_bound else peak_mfma,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": gbs / PEAK_HBM_GBS if hbm_bound else tflops / peak_mfma, "traffic": traffic, "points_per_launch": P,
+            "note": "the slowest of the three MLP kernels, against the resource it uses most: HBM (achieved = algorithmic bytes "
+                    "per point x points / HIP-event time, peak 8 TB/s) or the matrix cores (achieved = algorithmic fp32-equivalent "
+                    "FLOP/s, peak = 2500 TFLOP/s dense f16 / 3 f16 MFMAs per fp32 product; the exact-f32 MFMA peak is 157.3)",
+            "mfma_frac": tflops / peak_mfma, "hbm_frac": gbs / PEAK_HBM_GBS, "executed_f16_tflops": tflops * MFMA_PER_PRODUCT,
+            "all_kernels": per_kernel,
             "all_kernels_ms": {k: v[0] * 1e3 for k, v in kernels.items()}}
 
 

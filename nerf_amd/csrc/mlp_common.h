@@ -236,16 +236,19 @@ __device__ __forceinline__ void swap_halves(float& a, float& b) {
     a = __uint_as_float(r[0]);
     b = __uint_as_float(r[1]);
 }
-// m: the largest |entry| this lane holds; the other half of the point's vector is in lane ^ 32.
-__device__ __forceinline__ PointScale point_scale(float m) {
-    float mo = m;
-    swap_halves(m, mo);
-    m = fmaxf(m, mo);
-    const int e = (int)(__float_as_uint(m) >> 23);          // biased exponent (m >= 0); 255 for inf / nan
+// max_bits: the bit pattern of the largest |entry| (a non-negative float).
+__device__ __forceinline__ PointScale scale_for_max(unsigned max_bits) {
+    const int e = (int)(max_bits >> 23);                     // biased exponent; 255 for inf / nan
     int se = 267 - e;                                        // largest entry -> [2^13, 2^14)
     se = se > 253 ? 253 : se;
     if (e == 0) se = 127;                                    // all zero (or subnormal): leave as it is
     return PointScale{__uint_as_float((unsigned)se << 23), __uint_as_float((unsigned)(254 - se) << 23)};
+}
+// m: the largest |entry| this lane holds; the other half of the point's vector is in lane ^ 32.
+__device__ __forceinline__ PointScale point_scale(float m) {
+    float mo = m;
+    swap_halves(m, mo);
+    return scale_for_max(__float_as_uint(fmaxf(m, mo)));
 }
 // The largest of a value over the wavefront (values compared as unsigned: non-negative floats order like their
 // bit patterns), in every lane; no LDS.
@@ -453,18 +456,6 @@ __device__ __forceinline__ void dense_h3(WeightStream& ws, const f32x16 (&in)[KT
 
 // bf16 x 3 splits (v = h + m + l, 8 bits each) of the weight-gradient kernels that split per wave
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-// {bf16(a), bf16(b)} rounded to nearest even, a in the low half
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-template <int OFF_BYTES>
-__device__ __forceinline__ bf16x8 lds_read_bf8(unsigned addr) {
-    bf16x8 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF_BYTES));
-    return r;
-}
 __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -702,6 +693,9 @@ struct WgradPart {
     int k_first;             // X inputs below k_first are skipped (not written)
     int k_valid, k_valid2;   // inputs >= k_valid within a block are padding and are not written
     int n_valid;             // output rows >= n_valid are padding and are not written
+    const unsigned* amaxY;   // the largest |entry| of dY, X, X2 as float bit patterns in device memory (the split-f16
+    const unsigned* amaxX;   // shapes scale their operands by them); null: the matrix is used as it is
+    const unsigned* amaxX2;
     int shape;         // index into the (NTW, KT, KT2) instantiation list
     int slabs;         // point slabs this part is split into
     int first_block;   // prefix sum of slabs
@@ -722,6 +716,13 @@ struct SkinnyPart {
     float* dbias;     // [C]
     int ldY, ldX, c0, C, K;
 };
+
+// Largest-|entry| bookkeeping of the split-f16 weight gradients: every wavefront of the kernel that writes a
+// matrix stores the largest |entry| of its 32 rows (float bits) at per_wave[16 * tile + slot]; this reduces the 16
+// slots over all tiles into out[0..15].  (Plain stores and one small launch: atomics on 16 shared words from
+// 25,000 wavefronts cost the writing kernel 0.8 ms.)
+constexpr int AMAX_SLOTS = 16;
+int launch_amax_reduce(const unsigned* per_wave, long long tiles, unsigned* out, hipStream_t stream);
 
 // Fills slabs/first_block/total_blocks and launches one workgroup per slab.
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream);

@@ -1,5 +1,5 @@
 // Kernels shared by the fused MLPs: weight packing, the weight-gradient GEMMs
-// (contraction over points on the exact-f32 MFMA) and the small-head gradients.
+// (contraction over points on split-f16, split-bf16 or exact-f32 MFMAs) and the small-head gradients.
 #include "mlp_common.h"
 
 namespace nerf {
@@ -61,6 +61,28 @@ __global__ void pack_kernel(PackJobs jobs, float* __restrict__ packed) {
 int launch_pack(const PackJobs& jobs, float* packed, hipStream_t stream) {
     hipLaunchKernelGGL(pack_kernel, dim3(64, jobs.n), dim3(256), 0, stream, jobs, packed);
     return check_launch("pack");
+}
+
+// ------------------------------------------------------- operand maxima ----
+__global__ __launch_bounds__(1024) void amax_reduce_kernel(const unsigned* __restrict__ per_wave, long long tiles,
+                                                           unsigned* __restrict__ out) {
+    __shared__ unsigned part[16];
+    const int slot = blockIdx.x;
+    unsigned m = 0;
+    for (long long t = threadIdx.x; t < tiles; t += blockDim.x) m = max(m, per_wave[t * AMAX_SLOTS + slot]);
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = max(m, part[w]);
+        out[slot] = m;
+    }
+}
+
+int launch_amax_reduce(const unsigned* per_wave, long long tiles, unsigned* out, hipStream_t stream) {
+    hipLaunchKernelGGL(amax_reduce_kernel, dim3(AMAX_SLOTS), dim3(1024), 0, stream, per_wave, tiles, out);
+    return check_launch("amax_reduce");
 }
 
 // ---------------------------------------------------------------- wgrad ----
@@ -186,9 +208,10 @@ __device__ __forceinline__ void wgrad_mfma(const float (&a)[NTW], const float (&
 
 // Adds a wave's accumulator tiles (and bias sums) to the gradient tensors.
 // dW[n0 + 32nt + rowmap(r,s)][col + i]: per register two 128-byte row segments
+// scale, scale2: factors applied to the accumulators of the X and X2 blocks on their way out.
 template <int NTW, int KT, int KT2>
 __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[NTW][KT + KT2], float (&bsum)[NTW], int n0,
-                                             int i, int s, bool with_bias = true) {
+                                             int i, int s, bool with_bias = true, float scale = 1.0f, float scale2 = 1.0f) {
     constexpr int KTT = KT + KT2;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -200,7 +223,9 @@ __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = n0 + 32 * nt + rowmap(r, s);
-                    if (n < pt.n_valid) atomicAdd(pt.dW + (size_t)n * pt.ldW + col, acc[nt][kt][r]);
+                    float v = acc[nt][kt][r];
+                    asm volatile("" : "+v"(v)::"memory");   // one product at a time: hoisted above the atomics they all spill
+                    if (n < pt.n_valid) atomicAdd(pt.dW + (size_t)n * pt.ldW + col, v * (kt < KT ? scale : scale2));
                 }
             }
         }
@@ -430,17 +455,21 @@ __device__ __forceinline__ void wgrad_part_x6(const WgradPart& pt, long long p_b
     wgrad_finish<NTW, KT, KT2>(pt, acc, bsum, n0, i, s);
 }
 
-// ---- The same product with the operands split once per workgroup ----------------------------------
-// Above, every wave splits each X tile it multiplies with: four times the work per workgroup, and
-// the conversions (~6.5 instructions per value) rival the MFMAs.  Here a k-step (16 points) of dY and X
-// is loaded into registers once, split there, and stored to LDS as ready bf16 operands:
-// [tile][h, m, l][operand lane][8 points], which every wave then reads with one 16-byte load per operand.
+// ---- The same product on split-f16 MFMAs, the operands split once per workgroup ---------------------
+// Above, every wave splits each X tile it multiplies with: four times the work per workgroup.  Here a k-step
+// (16 points) of dY and X is loaded into registers once, split there into two f16 pieces (see dense_h3 in
+// mlp_common.h: v = h + l, three MFMAs per product) and stored to LDS as ready operands:
+// [tile][h, l][operand lane][8 points], which every wave then reads with one 16-byte load per operand.
+// Both matrices are first scaled by a power of two that brings their largest |entry| (found by the kernels that
+// wrote them) into [2^13, 2^14): both residuals then stay f16 normal numbers for every entry within 2^-16 of
+// the largest, and smaller entries keep an absolute error below 2^-38 of the largest.  The product of the two
+// scales is removed when the accumulators are added to the gradient.
 // Three buffers of one k-step rotate: k-step s is multiplied while k-step s+2 is split and stored and
 // k-step s+4 is on its way from memory, so the one barrier per k-step only has skew to wait for.
 // A tile's stride is padded by 16 bytes so that the four tiles a wave stores at once fall on different banks.
-constexpr int PK_TILE_BYTES = 3 * 1024 + 16;
+constexpr int PK_TILE_BYTES = 2 * 1024 + 16;
 constexpr int PK_BUF_BYTES = 16 * PK_TILE_BYTES;
-constexpr int PK_CHUNKS = 68;   // steps of the operand split of a k-step (see wgrad_part_pk)
+constexpr int PK_CHUNKS = 40;   // steps of the operand split of a k-step (see wgrad_part_pk)
 static_assert(3 * PK_BUF_BYTES <= WG_LDS_FLOATS * 4, "operand buffers exceed the LDS allocation");
 
 template <int OFF_BYTES>
@@ -448,15 +477,19 @@ __device__ __forceinline__ void lds_write_u4(unsigned addr, u32x4 v) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF_BYTES) : "memory");
 }
 
+__device__ __forceinline__ PointScale part_scale(const unsigned* amax) {
+    return amax ? scale_for_max(*amax) : PointScale{1.0f, 1.0f};
+}
 
 template <int NTW, int KT, int KT2, int GROUP>
 __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
                                               float* lds) {
-    constexpr int NT = 4 * NTW, KTT = KT + KT2, TILES = NT + KTT, J = KTT / GROUP, NM = 6 * NTW * GROUP;
-    static_assert(TILES <= 16 && KTT % GROUP == 0 && (NTW + GROUP) * 3 <= NM, "shape");
+    constexpr int NT = 4 * NTW, KTT = KT + KT2, TILES = NT + KTT, J = KTT / GROUP, NM = 3 * NTW * GROUP;
+    static_assert(TILES <= 16 && KTT % GROUP == 0 && (NTW + GROUP) * 2 <= NM, "shape");
     constexpr int PTAIL = 6;   // the last 1/PTAIL of a k-step's MFMAs carry no split work
     const int i = lane & 31, s = lane >> 5;
     const int n0 = wave * NTW * 32;
+    const PointScale scY = part_scale(pt.amaxY), scX = part_scale(pt.amaxX), scX2 = part_scale(pt.amaxX2);
     f32x16 acc[NTW][KTT];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -467,21 +500,24 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
 
     // producer role: columns 4pj .. 4pj+3 of tile T (dY tiles first, then X, then X2), points 8ps .. 8ps+7 of a k-step
     // lane bits: 0 = column quad bit 0, 1-2 = tile, 3-4 = column quad bits 1-2, 5 = point half: any eight (and
-    // sixteen) consecutive lanes store to different banks (tile stride = 193 x 16 B, column quad = 4 x 16 B)
+    // sixteen) consecutive lanes store to different banks (tile stride = 129 x 16 B, column quad = 4 x 16 B)
     const int pj = (lane & 1) | ((lane >> 2) & 6), ptl = (lane >> 1) & 3, ps = lane >> 5;
     const int T = 4 * wave + ptl;
     const bool active = T < TILES;
     const float* src = pt.dY + 4 * pj;   // lanes without a tile load (and store) something harmless
     long long ld = pt.ldY;
+    float c1 = scY.s;                    // the scale of this lane's matrix
     if (T < NT) {
         src = pt.dY + 32 * T + 4 * pj;
         ld = pt.ldY;
     } else if (T < NT + KT) {
         src = pt.X + 32 * (T - NT) + 4 * pj;
         ld = pt.ldX;
+        c1 = scX.s;
     } else if (active) {
         src = pt.X2 + 32 * (T - NT - KT) + 4 * pj;
         ld = pt.ldX2;
+        c1 = scX2.s;
     }
     src += 8 * ps * ld;
     const unsigned lds0 = lds_addr(lds);
@@ -497,70 +533,61 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
         R[decltype(cu)::value][decltype(cq)::value] = make_float4(ld4[0], ld4[1], ld4[2], ld4[3]);
     };
     auto load_raw = [&](auto cu, long long p) { static_for<0, 8>([&](auto cq) { load_row(cu, cq, p); }); };
-    // Splitting a k-step is 68 chunks of at most six mutually independent instructions, one chunk per MFMA:
+    // Splitting a k-step is 40 chunks of at most six mutually independent instructions, one chunk per MFMA:
     // a dependent instruction issued right behind its producer waits ~9 clocks and holds up the MFMA queued
-    // behind it, whereas up to six independent ones issue under an MFMA for free.  Chunk 14e + 7g + level
-    // is one level of the split of rows 2e, 2e+1 of columns 2g, 2g+1 (bf16 pair h, its residual, pair m, its
-    // residual, pair l); chunks 56-67 store the three operands of the four finished columns.  After the last chunk of a row pair its
+    // behind it, whereas up to six independent ones issue under an MFMA for free.  Chunk 8e + 4g + level
+    // is one level of the split of rows 2e, 2e+1 of columns 2g, 2g+1 (scale, f16 pair h, its residual, pair l);
+    // chunks 32-39 store the two operands of the four finished columns.  After the last chunk of a row pair its
     // rows of the k-step after next are requested, so the requests spread over the k-step.
-    unsigned PH[4][4], PM[4][4], PL[4][4];   // [column][row pair], two bf16 each
-    float t_r0[2], t_r1[2], t_f0[2], t_f1[2], t_sum[2];
+    unsigned PH[4][4], PL[4][4];   // [column][row pair], two f16 each
+    float t_x0[2], t_x1[2], t_sum[2];
     auto chunk = [&](auto cu, auto ck, unsigned wr, float live, long long p_next) {
         constexpr int u = decltype(cu)::value, k = decltype(ck)::value;
-        if constexpr (k < 56) {
-            constexpr int e = k / 14, g = (k % 14) / 7, lv = k % 7;
+        if constexpr (k < 32) {
+            constexpr int e = k / 8, g = (k % 8) / 4, lv = k % 4;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c = 2 * g + j;
                 const float x0 = c == 0 ? R[u][2 * e].x : c == 1 ? R[u][2 * e].y : c == 2 ? R[u][2 * e].z : R[u][2 * e].w;
                 const float x1 = c == 0 ? R[u][2 * e + 1].x : c == 1 ? R[u][2 * e + 1].y : c == 2 ? R[u][2 * e + 1].z : R[u][2 * e + 1].w;
                 if constexpr (lv == 0) {
-                    PH[c][e] = cvt_pk_bf16(x0, x1);
+                    t_x0[j] = x0 * c1;
+                    t_x1[j] = x1 * c1;
                     t_sum[j] = x0 + x1;
                 } else if constexpr (lv == 1) {
-                    t_f0[j] = __uint_as_float(PH[c][e] << 16);
-                    t_f1[j] = __uint_as_float(PH[c][e] & 0xffff0000u);
+                    PH[c][e] = cvt_pk_f16(t_x0[j], t_x1[j]);
                     bsum[c] = fmaf(live, t_sum[j], bsum[c]);
                 } else if constexpr (lv == 2) {
-                    t_r0[j] = x0 - t_f0[j];
-                    t_r1[j] = x1 - t_f1[j];
-                } else if constexpr (lv == 3) {
-                    PM[c][e] = cvt_pk_bf16(t_r0[j], t_r1[j]);
-                } else if constexpr (lv == 4) {
-                    t_f0[j] = __uint_as_float(PM[c][e] << 16);
-                    t_f1[j] = __uint_as_float(PM[c][e] & 0xffff0000u);
-                } else if constexpr (lv == 5) {
-                    t_r0[j] = t_r0[j] - t_f0[j];
-                    t_r1[j] = t_r1[j] - t_f1[j];
+                    t_x0[j] = sub_f16<0>(t_x0[j], PH[c][e]);
+                    t_x1[j] = sub_f16<1>(t_x1[j], PH[c][e]);
                 } else {
-                    PL[c][e] = cvt_pk_bf16(t_r0[j], t_r1[j]);
+                    PL[c][e] = cvt_pk_f16(t_x0[j], t_x1[j]);
                 }
             }
-            if constexpr (k % 14 == 13) {
+            if constexpr (k % 8 == 7) {
                 load_row(cu, std::integral_constant<int, 2 * e>{}, p_next);
                 load_row(cu, std::integral_constant<int, 2 * e + 1>{}, p_next);
             }
         } else {   // one store per chunk: the four waves are in step and their stores would arrive together
-            constexpr int c = (k - 56) / 3, part = (k - 56) % 3;
+            constexpr int c = (k - 32) / 2, part = (k - 32) % 2;
             if constexpr (part == 0) lds_write_u4<c * 16>(wr, u32x4{PH[c][0], PH[c][1], PH[c][2], PH[c][3]});
-            else if constexpr (part == 1) lds_write_u4<c * 16 + 1024>(wr, u32x4{PM[c][0], PM[c][1], PM[c][2], PM[c][3]});
-            else lds_write_u4<c * 16 + 2048>(wr, u32x4{PL[c][0], PL[c][1], PL[c][2], PL[c][3]});
+            else lds_write_u4<c * 16 + 1024>(wr, u32x4{PL[c][0], PL[c][1], PL[c][2], PL[c][3]});
         }
     };
-    bf16x8 as[2][NTW][3], bs[2][GROUP][3];
-    auto read_a1 = [&](unsigned buf, auto ce, bf16x8 (&o)[NTW][3]) {
+    f16x8 as[2][NTW][2], bs[2][GROUP][2];
+    auto read_a1 = [&](unsigned buf, auto ce, f16x8 (&o)[NTW][2]) {
         constexpr int e = decltype(ce)::value;
-        o[e / 3][e % 3] = lds_read_bf8<(e / 3) * PK_TILE_BYTES + (e % 3) * 1024>(buf + rd_a_off);
+        o[e / 2][e % 2] = lds_read_h8<(e / 2) * PK_TILE_BYTES + (e % 2) * 1024>(buf + rd_a_off);
     };
-    auto read_b1 = [&](unsigned buf, auto cc, auto ce, bf16x8 (&o)[GROUP][3]) {
+    auto read_b1 = [&](unsigned buf, auto cc, auto ce, f16x8 (&o)[GROUP][2]) {
         constexpr int k0 = GROUP * decltype(cc)::value, e = decltype(ce)::value;
-        o[e / 3][e % 3] = lds_read_bf8<(NT + k0 + e / 3) * PK_TILE_BYTES + (e % 3) * 1024>(buf + rd_b_off);
+        o[e / 2][e % 2] = lds_read_h8<(NT + k0 + e / 2) * PK_TILE_BYTES + (e % 2) * 1024>(buf + rd_b_off);
     };
-    auto read_a = [&](unsigned buf, bf16x8 (&o)[NTW][3]) {
-        static_for<0, NTW * 3>([&](auto ce) { read_a1(buf, ce, o); });
+    auto read_a = [&](unsigned buf, f16x8 (&o)[NTW][2]) {
+        static_for<0, NTW * 2>([&](auto ce) { read_a1(buf, ce, o); });
     };
-    auto read_b = [&](unsigned buf, auto cc, bf16x8 (&o)[GROUP][3]) {
-        static_for<0, GROUP * 3>([&](auto ce) { read_b1(buf, cc, ce, o); });
+    auto read_b = [&](unsigned buf, auto cc, f16x8 (&o)[GROUP][2]) {
+        static_for<0, GROUP * 2>([&](auto ce) { read_b1(buf, cc, ce, o); });
     };
 
     // prologue: k-steps 0 and 1 into buffers 0 and 1, k-steps 2 and 3 requested
@@ -589,30 +616,30 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
 #pragma unroll
                 for (int g = 0; g < GROUP; ++g)
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) asm volatile("" : "+v"(bs[par][g][e]));
+                    for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(bs[par][g][e]));
                 if constexpr (c == 0) {
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                        for (int e = 0; e < 3; ++e) asm volatile("" : "+v"(as[u][nt][e]));
+                        for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(as[u][nt][e]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_sched_barrier(0);
+                // MFMAs of item c, smallest terms first: l * h, h * l, h * h
                 static_for<0, NM>([&](auto cm) {
                     constexpr int m = decltype(cm)::value, term = m / (NTW * GROUP), nt = (m / GROUP) % NTW, g = m % GROUP;
-                    constexpr int ai = term == 0 ? 2 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 1 : 0;
-                    constexpr int bi = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
-                    acc[nt][k0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[u][nt][ai], bs[par][g][bi], acc[nt][k0 + g], 0, 0, 0);
+                    constexpr int ai = term == 0 ? 1 : 0;
+                    constexpr int bi = term == 1 ? 1 : 0;
+                    acc[nt][k0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[u][nt][ai], bs[par][g][bi], acc[nt][k0 + g], 0, 0, 0);
                     asm volatile("" : "+a"(acc[nt][k0 + g]));
                     // The next item's operands, one request per MFMA (the four waves run in step: bursts from all of
                     // them at once queue up in the LDS); after the last item the next k-step's dY tiles and first
                     // item, whose buffer was complete a barrier ago.
                     if constexpr (c + 1 < J) {
-                        if constexpr (m < GROUP * 3) read_b1(cur, std::integral_constant<int, c + 1>{}, cm, bs[par ^ 1]);
+                        if constexpr (m < GROUP * 2) read_b1(cur, std::integral_constant<int, c + 1>{}, cm, bs[par ^ 1]);
                     } else {
-                        if constexpr (m < NTW * 3) read_a1(nxt, cm, as[u ^ 1]);
-                        else if constexpr (m < NTW * 3 + GROUP * 3)
-                            read_b1(nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, m - NTW * 3>{}, bs[par ^ 1]);
+                        if constexpr (m < NTW * 2) read_a1(nxt, cm, as[u ^ 1]);
+                        else if constexpr (m < NTW * 2 + GROUP * 2)
+                            read_b1(nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, m - NTW * 2>{}, bs[par ^ 1]);
                     }
                     // position within the k-step: its share of the chunks, which end PSLOTS MFMAs in so that
                     // the last stores have landed when the k-step's barrier comes
@@ -632,7 +659,7 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
     float zero[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) zero[nt] = 0.0f;
-    wgrad_finish<NTW, KT, KT2>(pt, acc, zero, n0, i, s, false);
+    wgrad_finish<NTW, KT, KT2>(pt, acc, zero, n0, i, s, false, scY.inv * scX.inv, scY.inv * scX2.inv);   // the scales come off
     if (pt.dbias && T < NT) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)

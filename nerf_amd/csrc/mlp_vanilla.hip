@@ -46,14 +46,17 @@ constexpr int H = 96;        // 8 x [P32][256]
 constexpr int FEAT = H + 8 * 256;
 constexpr int HR = FEAT + 256;  // [P32][128]
 constexpr int MASK = HR + 128;  // [P32/32][9][64][4] u32
-constexpr int PER_POINT = MASK + 72;
+constexpr int AMAX = MASK + 72; // [P32/32][16] u32: largest |entry| per wavefront of each saved matrix (float bits, slots
+constexpr int PER_POINT = AMAX + 4;   // below); their maxima over the wavefronts in the 16 words at float offset 2 * P32
+// slots of the forward maxima: x_enc, h0..h7, feat, hr, d_enc
+constexpr int SLOT_XE = 0, SLOT_H = 1, SLOT_FEAT = 9, SLOT_HR = 10, SLOT_DE = 11;
 // backward workspace
 constexpr int DY = 0;           // 8 x [P32][256]
 constexpr int DFEAT = 8 * 256;
 constexpr int DYR = DFEAT + 256;   // [P32][128]
 constexpr int DOUT4 = DYR + 128;   // [P32][4] = (d sigma_pre, d rgb_pre[3])
-constexpr int AMAX = DOUT4 + 4;    // the first 16 words: largest |entry| of each gradient matrix (float bits)
-constexpr int PER_POINT2 = AMAX + 4;
+constexpr int AMAX2 = DOUT4 + 4;   // the same for the gradient matrices: slots d y0..d y7, d feat, d hr
+constexpr int PER_POINT2 = AMAX2 + 4;
 }  // namespace vw
 
 struct TileIdx {
@@ -128,10 +131,20 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
     const float dir0 = dirs[3 * dr], dir1 = dirs[3 * dr + 1], dir2 = dirs[3 * dr + 2];
     uint4* mask_out = SAVE ? reinterpret_cast<uint4*>(ws + ix.P32 * vw::MASK) + (ix.tile * 9) * 64 + lane : nullptr;
+    // Training: the wave's largest |entry| of every matrix it saves, from which the weight-gradient kernel derives
+    // the scale of its operands (see launch_amax_reduce).
+    unsigned* amax = SAVE ? reinterpret_cast<unsigned*>(ws + ix.P32 * vw::AMAX) + ix.tile * AMAX_SLOTS : nullptr;
+    auto publish_max = [&](float m, int slot) {
+        if (SAVE) {
+            const unsigned wm = wave_max_u32(__float_as_uint(m));
+            if (lane == 0) amax[slot] = wm;
+        }
+    };
 
     f32x16 xe[2];
     pe_tiles<2, 10>(xe, x0, x1, x2, h);
     const float mx = abs_max<2>(xe);
+    publish_max(mx, vw::SLOT_XE);
     ws_ready();
 
     f32x16 hc[8], acc[8];
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
         for (int t = 0; t < 8; ++t) hc[t] = acc[t];
         if (SAVE) mask_out[l * 64] = relu_bits<8>(hc);
         mh = abs_max<8>(hc);
+        publish_max(mh, vw::SLOT_H + l);
     };
     // layer 0
     PointScale sc = point_scale(mx);
@@ -177,12 +191,18 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
     pe_tiles<1, 4>(de, dir0, dir1, dir2, h);
-    sc = point_scale(abs_max<1>(de, abs_max<8>(acc)));
+    {
+        const float mf = abs_max<8>(acc), md = abs_max<1>(de);
+        publish_max(mf, vw::SLOT_FEAT);
+        publish_max(md, vw::SLOT_DE);
+        sc = point_scale(fmaxf(mf, md));
+    }
     f32x16 hr[4];
     dense_layer<8, 4, SAVE, true>(wst, acc, sc.s, hr, rows_of(vw::FEAT));
     dense_layer<1, 4, SAVE>(wst, de, sc.s, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
     finish_tiles<4, true>(hr, sc.inv, const_at(vp::S_B1), h);
     if (SAVE) {
+        publish_max(abs_max<4>(hr), vw::SLOT_HR);
         save_tiles<4>(tb, ws + ix.P32 * vw::HR + ix.tile * 32 * 128, 128, hr);
         mask_out[8 * 64] = relu_bits<4>(hr);
     }
@@ -193,9 +213,9 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     }
 }
 
-// Backward-data chain.  Emits d(pre-activation) of every layer row-major into ws2, and the largest |entry| of
-// each of those matrices (as the bit pattern of a non-negative float) into amax[0..9]: layer 0..7, feature
-// layer, colour hidden layer.  The weight-gradient kernel scales its operands by them.
+// Backward-data chain.  Emits d(pre-activation) of every layer row-major into ws2, and per wavefront the largest
+// |entry| of each of those matrices (as the bit pattern of a non-negative float) into amax[16 * tile + 0..9]:
+// layer 0..7, feature layer, colour hidden layer.
 __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __restrict__ d_rgb,
                                                                const float* __restrict__ d_sigma, long long P,
                                                                const float* __restrict__ pk,
@@ -240,11 +260,11 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
     if (h == 0) *reinterpret_cast<float4*>(ws2 + ix.P32 * vw::DOUT4 + ix.gp * 4) = make_float4(dps, dpre[0], dpre[1], dpre[2]);
     ws_ready();
 
-    // The wave's largest |entry| of a gradient matrix joins the global maximum.  A tile beyond the last one repeats
-    // the last tile's values, which changes nothing.
+    // The wave's largest |entry| of each gradient matrix (see launch_amax_reduce).
+    unsigned* amax_w = amax + ix.tile * AMAX_SLOTS;
     auto publish_max = [&](float m, int slot) {
         const unsigned wm = wave_max_u32(__float_as_uint(m));
-        if (lane == 0) atomicMax(amax + slot, wm);
+        if (lane == 0) amax_w[slot] = wm;
     };
 
     // d hr = W2^T d rgb_pre, masked by the ReLU of the colour hidden layer
@@ -400,10 +420,14 @@ extern "C" int nerf_mlp_vanilla_fwd(const float* x, const float* dirs, int dirs_
     NERF_REQUIRE(x && dirs && packed && rgb && sigma, "nerf_mlp_vanilla_fwd: null pointer");
     NERF_REQUIRE(P >= 0 && dirs_div >= 1, "nerf_mlp_vanilla_fwd: P=%lld dirs_div=%d", (long long)P, dirs_div);
     const dim3 grid((unsigned)ceil_div(P, 128)), block(256);
-    if (ws)
+    if (ws) {
         hipLaunchKernelGGL(vanilla_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, x, dirs, (long long)P, packed, rgb,
                            sigma, ws, dirs_div);
-    else
+        if (int rc = check_launch("nerf_mlp_vanilla_fwd")) return rc;
+        const long long P32 = (P + 31) / 32 * 32;
+        unsigned* amax = reinterpret_cast<unsigned*>(ws + P32 * vw::AMAX);
+        return launch_amax_reduce(amax, P32 / 32, amax + 2 * P32, (hipStream_t)stream);
+    } else
         hipLaunchKernelGGL(vanilla_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, x, dirs, (long long)P, packed,
                            rgb, sigma, ws, dirs_div);
     return check_launch("nerf_mlp_vanilla_fwd");
@@ -418,11 +442,12 @@ extern "C" int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, in
     NERF_REQUIRE(P >= 0, "nerf_mlp_vanilla_bwd: P=%lld", (long long)P);
     hipStream_t st = (hipStream_t)stream;
     if (phases & 1) {
-        unsigned* amax = reinterpret_cast<unsigned*>(ws2 + (size_t)((P + 31) / 32 * 32) * vw::AMAX);
-        if (hipMemsetAsync(amax, 0, 16 * sizeof(unsigned), st) != hipSuccess) return fail(NERF_ELAUNCH, "nerf_mlp_vanilla_bwd: memset failed");
+        const long long P32 = (P + 31) / 32 * 32;
+        unsigned* amax = reinterpret_cast<unsigned*>(ws2 + P32 * vw::AMAX2);
         hipLaunchKernelGGL(vanilla_bwd_data_kernel, dim3((unsigned)ceil_div(P, 128)), dim3(256), 0, st, d_rgb, d_sigma,
                            (long long)P, packed, rgb, sigma, ws, ws2, amax);
         if (int rc = check_launch("nerf_mlp_vanilla_bwd(data)")) return rc;
+        if (int rc = launch_amax_reduce(amax, P32 / 32, amax + 2 * P32, st)) return rc;
     }
     if (!(phases & 2)) return NERF_OK;
 
@@ -437,17 +462,26 @@ extern "C" int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, in
     const float* DYR = ws2 + P32 * vw::DYR;
     const float* DOUT4 = ws2 + P32 * vw::DOUT4;
     const int xe_col = skip_h_first ? 256 : 0, h_col = skip_h_first ? 0 : 63;
+    const unsigned* amax_f = reinterpret_cast<const unsigned*>(ws + P32 * vw::AMAX) + 2 * P32;     // forward maxima, see vw::SLOT_*
+    const unsigned* amax_b = reinterpret_cast<const unsigned*>(ws2 + P32 * vw::AMAX2) + 2 * P32;   // d y0..7, d feat, d hr
+    auto with_max = [&](WgradPart p, int slot_y, int slot_x, int slot_x2 = -1) {
+        p.amaxY = amax_b + slot_y;
+        p.amaxX = amax_f + slot_x;
+        p.amaxX2 = slot_x2 >= 0 ? amax_f + slot_x2 : nullptr;
+        return p;
+    };
     WgradParts parts{};
     int n = 0;
     // The narrow parts (4 MFMAs per k-step) wait on memory rather than on the MFMA pipe
     // and run longer than their MFMA count says: dispatch them first, the wide ones after.
     parts.part[n++] = wgrad_part_desc(DY(0), 256, XE, 64, grads[0], 63, 0, 63, grads[1], 2);
     parts.part[n++] = wgrad_part_desc(DY(4), 256, XE, 64, grads[8], 319, xe_col, 63, nullptr, 2);
-    parts.part[n++] = wgrad_part_desc(DYR, 128, FEAT, 256, grads[20], 283, 0, 256, grads[21], 1, DE, 32, 256, 27);
+    parts.part[n++] = with_max(wgrad_part_desc(DYR, 128, FEAT, 256, grads[20], 283, 0, 256, grads[21], 1, DE, 32, 256, 27), 9,
+                               vw::SLOT_FEAT, vw::SLOT_DE);
     for (int l = 1; l < 8; ++l)
-        parts.part[n++] = wgrad_part_desc(DY(l), 256, H(l - 1), 256, grads[2 * l], l == 4 ? 319 : 256, l == 4 ? h_col : 0, 256,
-                                          grads[2 * l + 1], 0);
-    parts.part[n++] = wgrad_part_desc(DFEAT, 256, H(7), 256, grads[18], 256, 0, 256, grads[19], 0);
+        parts.part[n++] = with_max(wgrad_part_desc(DY(l), 256, H(l - 1), 256, grads[2 * l], l == 4 ? 319 : 256,
+                                                   l == 4 ? h_col : 0, 256, grads[2 * l + 1], 0), l, vw::SLOT_H + l - 1);
+    parts.part[n++] = with_max(wgrad_part_desc(DFEAT, 256, H(7), 256, grads[18], 256, 0, 256, grads[19], 0), 8, vw::SLOT_H + 7);
     parts.n = n;
     if (int rc = launch_wgrad(parts, P32, st)) return rc;
 
