@@ -272,15 +272,14 @@ __device__ __forceinline__ float abs_max(const f32x16 (&a)[NT], float m = 0.0f) 
 
 // The weight stream of the f16 x 3 layers.  The packed layers of a kernel lie in memory in the order they are
 // used and every chunk is 16 KiB (a k-step of 8 out tiles, or two k-steps of 4), so the stream is one linear
-// run of chunks through H3_RING rotating LDS buffers: while chunk c is multiplied, chunk c+1 has landed, chunks
+// run of chunks through RING rotating LDS buffers: while chunk c is multiplied, chunk c+1 has landed, chunks
 // c+2 .. c+RING-2 are on their way and the copies of chunk c+RING-1 go out (in the middle of chunk c, after the
 // barrier that frees the buffer of chunk c-1).  The wait for chunk c+1 in the middle of chunk c so concerns
 // copies issued RING-2 chunks earlier: vector memory operations complete in issue order, and a shorter ring would
 // make that wait also cover the row stores of the previous k-step, whose acknowledgement takes longer than a
 // k-step.  Past the end of the stream the last chunk is copied again, so that the count of operations in flight
 // stays what the waits assume.
-constexpr int H3_RING = 4;
-constexpr int H3_LDS_FLOATS = H3_RING * H3_CHUNK_FLOATS;
+constexpr int h3_lds_floats(int ring) { return ring * H3_CHUNK_FLOATS; }
 constexpr int H3_PIECES = H3_CHUNK_FLOATS / 1024;   // 1 KiB pieces per wave per chunk
 __device__ __forceinline__ const float* h3_next_chunk(const WeightStream& ws) {
     return ws.next < ws.end ? ws.next : ws.end - H3_CHUNK_FLOATS;
@@ -292,31 +291,39 @@ __device__ __forceinline__ void h3_copy_chunk(WeightStream& ws, int buf) {
     ws.next += H3_CHUNK_FLOATS;
 }
 // Start the stream at `first`: request its first RING-1 chunks.  ws_ready() must follow before the first dense_h3().
+template <int RING>
 __device__ __forceinline__ void h3_prime(WeightStream& ws, const float* first, const float* end) {
     ws.next = first;
     ws.end = end;
 #pragma unroll
-    for (int c = 0; c < H3_RING - 1; ++c) h3_copy_chunk(ws, c);
+    for (int c = 0; c < RING - 1; ++c) h3_copy_chunk(ws, c);
     ws.g3 = 0;
 }
 
-// Row stores a layer issues in its k-step k (none in k-step 0, and nothing is assumed about the previous layer).
+// Row stores a layer issues in its k-step k (none in k-step 0, and nothing is assumed about the previous layer),
+// and in k-steps k0 .. k1.
 template <bool DRAIN>
 constexpr int h3_stores(int k) { return DRAIN && k > 0 ? 2 : 0; }
+template <bool DRAIN>
+constexpr int h3_stores(int k0, int k1) {
+    int n = 0;
+    for (int k = k0; k <= k1; ++k) n += h3_stores<DRAIN>(k);
+    return n;
+}
 
 // acc[ot] (+)= W_tile(ot, kt) * (scale * in[kt]), the layer's weights being the next KT * OT / 4 chunks of the
 // stream.  A chunk is two groups of 12 MFMAs (4 out tiles x 3 terms): the two halves of a k-step (OT = 8) or two
 // k-steps (OT = 4); one barrier per chunk, between its groups.
 // ZERO: the accumulators start from zero (their contents on entry are ignored).
 // DRAIN: also write the input tiles (unscaled) to sv.rows0, tile t during k-steps 2t and 2t+1.
-template <int KT, int OT, bool DRAIN = false, bool ZERO = false>
+template <int RING, int KT, int OT, bool DRAIN = false, bool ZERO = false>
 __device__ __forceinline__ void dense_h3(WeightStream& ws, const f32x16 (&in)[KT], float scale, f32x16 (&acc)[OT],
                                          TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
     static_assert(OT == 4 || OT == 8, "out tiles are processed four at a time, two groups per chunk");
     constexpr int S = 2 * KT, G = OT / 4, NCH = S * G / 2;
     constexpr int NM = 12, NSPLIT = 6, SLOTS = NM * G;   // MFMAs per group; steps of the operand split; MFMAs per k-step
-    constexpr int RMASK = H3_RING - 1;
-    static_assert((H3_RING & RMASK) == 0, "the ring is indexed with a mask");
+    constexpr int RMASK = RING - 1;
+    static_assert(RING >= 4 && (RING & RMASK) == 0, "the ring is indexed with a mask");
     f16x8 a[2][8];                   // operands of a group of 4 out tiles (tile*2 + piece), double-buffered
     u32x4 b[3];                      // this k-step's B pieces (h, h'', l); the next one's are built in nh, nh2, nl
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};   // two row blocks on their way out
@@ -395,10 +402,10 @@ __device__ __forceinline__ void dense_h3(WeightStream& ws, const f32x16 (&in)[KT
                         // (RING-2 chunks ago) may stay in flight: the copies of the chunks after it and the row
                         // stores since, which follow their k-step's copies.  This layer's k-step 0 has no stores;
                         // at the start of a layer only the previous layer's copies are counted.
-                        constexpr int YOUNGER = (H3_RING - 3) * H3_PIECES +
-                                                (ch == 0 ? 0 : G == 2 ? h3_stores<DRAIN>(ch - 1) + h3_stores<DRAIN>(ch)
-                                                                      : h3_stores<DRAIN>(2 * ch - 3) + h3_stores<DRAIN>(2 * ch - 2) +
-                                                                        h3_stores<DRAIN>(2 * ch - 1) + h3_stores<DRAIN>(2 * ch));
+                        constexpr int YOUNGER = (RING - 3) * H3_PIECES +
+                                                (ch == 0 ? 0 : G == 2 ? h3_stores<DRAIN>(ch - (RING - 3), ch)
+                                                                      : h3_stores<DRAIN>(2 * (ch - (RING - 2)) + 1, 2 * ch));
+                        static_assert(YOUNGER < 64, "s_waitcnt vmcnt holds 6 bits");
                         ws_ready<YOUNGER>();
                         copy_src = h3_next_chunk(ws);
                         ws.next += H3_CHUNK_FLOATS;
@@ -413,7 +420,7 @@ __device__ __forceinline__ void dense_h3(WeightStream& ws, const f32x16 (&in)[KT
                 }
                 // between them the copies of chunk ch+RING-1 (after the barrier of this group),
                 if constexpr (gg == 1 && m >= 2 && m % 2 == 0 && m <= 2 * H3_PIECES)
-                    ws_copy_piece(ws, copy_src, ws.lds + ((b0 + H3_RING - 1) & RMASK) * H3_CHUNK_FLOATS, m / 2 - 1);
+                    ws_copy_piece(ws, copy_src, ws.lds + ((b0 + RING - 1) & RMASK) * H3_CHUNK_FLOATS, m / 2 - 1);
                 // then the two row blocks read during the previous k-step leave for memory (non-temporal: they are
                 // read again only by another kernel, after gigabytes of other traffic),
                 if constexpr (DRAIN && g == 0 && s > 0 && (m == 9 || m == 10)) {

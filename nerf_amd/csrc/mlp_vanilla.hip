@@ -82,27 +82,25 @@ __device__ __forceinline__ void tile_index(long long P, TileIdx& ix) {
     ix.P32 = (P + 31) / 32 * 32;
 }
 
-// One dense layer through the weight stream (split-f16 MFMAs); the stream knows which layer comes next.
-template <int KT, int OT, bool DRAIN = false, bool ZERO = false>
-__device__ __forceinline__ void dense_layer(WeightStream& ws, const f32x16 (&in)[KT], float scale, f32x16 (&acc)[OT],
-                                            TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
-    dense_h3<KT, OT, DRAIN, ZERO>(ws, in, scale, acc, sv);
-}
-constexpr int STREAM_LDS_FLOATS = H3_LDS_FLOATS;
-constexpr int CONST_LDS_OFF = STREAM_LDS_FLOATS + 4 * TILE_LDS_FLOATS;
-constexpr int KERNEL_LDS_FLOATS = CONST_LDS_OFF + vp::CONST_FLOATS;
-constexpr int MASK_LDS_OFF = KERNEL_LDS_FLOATS;                       // backward: the ReLU bits of the wave's tile,
-constexpr int BWD_LDS_FLOATS = MASK_LDS_OFF + 4 * 9 * 256;            // 9 layers x 1 KiB per wave
-static_assert(BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS of a workgroup");
+// LDS of the two kernels: [weight ring][4 transposition tiles][biases and head weights][backward: ReLU bits].
+// The forward kernel has room for a ring of 8 chunks: the wait for a chunk then concerns copies issued six chunks
+// earlier, and the row stores of the five k-steps since may still be in flight.
+constexpr int FWD_RING = 8, BWD_RING = 4;
+constexpr int tiles_lds_off(int ring) { return h3_lds_floats(ring); }
+constexpr int const_lds_off(int ring) { return tiles_lds_off(ring) + 4 * TILE_LDS_FLOATS; }
+constexpr int FWD_LDS_FLOATS = const_lds_off(FWD_RING) + vp::CONST_FLOATS;
+constexpr int MASK_LDS_OFF = const_lds_off(BWD_RING) + vp::CONST_FLOATS;   // backward: the ReLU bits of the wave's tile,
+constexpr int BWD_LDS_FLOATS = MASK_LDS_OFF + 4 * 9 * 256;                 // 9 layers x 1 KiB per wave
+static_assert(FWD_LDS_FLOATS * 4 <= 160 * 1024 && BWD_LDS_FLOATS * 4 <= 160 * 1024, "LDS of a workgroup");
 
 // The biases and head weights go to LDS with the first chunks of the weight stream; complete after ws_ready().
 // Returns the LDS byte address of packed offset S_BIAS.
-__device__ __forceinline__ unsigned copy_consts(float* lds, const float* __restrict__ pk, int wave, int lane) {
-    const WeightStream w{lds, 0, wave, lane};
+__device__ __forceinline__ unsigned copy_consts(float* lds_consts, const float* __restrict__ pk, int wave, int lane) {
+    const WeightStream w{lds_consts, 0, wave, lane};
 #pragma unroll
     for (int q = 0; q < (vp::CONST_FLOATS / 256 + 3) / 4; ++q)
-        if (4 * q + wave < vp::CONST_FLOATS / 256) ws_copy_piece(w, pk + vp::S_BIAS, lds + CONST_LDS_OFF, q);
-    return lds_addr(lds + CONST_LDS_OFF);
+        if (4 * q + wave < vp::CONST_FLOATS / 256) ws_copy_piece(w, pk + vp::S_BIAS, lds_consts, q);
+    return lds_addr(lds_consts);
 }
 __device__ __forceinline__ float lds_read1(unsigned addr) {
     float r;
@@ -117,16 +115,17 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
                                                           long long P, const float* __restrict__ pk,
                                                           float* __restrict__ rgb, float* __restrict__ sigma,
                                                           float* __restrict__ ws, int dirs_div) {
-    __shared__ __attribute__((aligned(16))) float lds[KERNEL_LDS_FLOATS];
+    constexpr int RING = FWD_RING;
+    __shared__ __attribute__((aligned(16))) float lds[FWD_LDS_FLOATS];
     TileIdx ix;
     tile_index(P, ix);
     const int lane = ix.lane, h = ix.h;
     WeightStream wst{lds, 0, ix.wave, lane};
-    const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
+    const TileBuf tb = tile_buf(lds + tiles_lds_off(RING) + ix.wave * TILE_LDS_FLOATS, lane);
     // the weight stream runs through the packed layers in the order they are used
-    const unsigned consts = copy_consts(lds, pk, ix.wave, lane);
+    const unsigned consts = copy_consts(lds + const_lds_off(RING), pk, ix.wave, lane);
     auto const_at = [&](int packed_off) { return consts + 4 * (packed_off - vp::S_BIAS); };
-    h3_prime(wst, pk + vp::F_L0, pk + vp::B_RGB0);
+    h3_prime<RING>(wst, pk + vp::F_L0, pk + vp::B_RGB0);
     const float x0 = x[3 * ix.lp], x1 = x[3 * ix.lp + 1], x2 = x[3 * ix.lp + 2];
     const long long dr = ix.lp / dirs_div;  // one direction per ray when dirs_div = samples per ray
     const float dir0 = dirs[3 * dr], dir1 = dirs[3 * dr + 1], dir2 = dirs[3 * dr + 2];
@@ -162,23 +161,23 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     };
     // layer 0
     PointScale sc = point_scale(mx);
-    dense_layer<2, 8, SAVE, true>(wst, xe, sc.s, acc, tile_save(tb, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64));
+    dense_h3<RING, 2, 8, SAVE, true>(wst, xe, sc.s, acc, tile_save(tb, ws + ix.P32 * vw::XE + ix.tile * 32 * 64, 64));
     finish_layer(0, sc.inv);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
         sc = point_scale(mh);
-        dense_layer<8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1)));
+        dense_h3<RING, 8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1)));
         finish_layer(l, sc.inv);
     }
     // skip connection: the layer-4 input is [x_enc | h] (either column order, see the packing), one scale for both
     sc = point_scale(fmaxf(mx, mh));
-    dense_layer<2, 8, false, true>(wst, xe, sc.s, acc);
-    dense_layer<8, 8, SAVE>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 3));
+    dense_h3<RING, 2, 8, false, true>(wst, xe, sc.s, acc);
+    dense_h3<RING, 8, 8, SAVE>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 3));
     finish_layer(4, sc.inv);
 #pragma unroll 1
     for (int l = 5; l < 8; ++l) {
         sc = point_scale(mh);
-        dense_layer<8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1)));
+        dense_h3<RING, 8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1)));
         finish_layer(l, sc.inv);
     }
     // density head: softplus(w.h + b)   (NeRF.py:90)
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(sp);
     // feature layer (no activation)      (NeRF.py:95)
     sc = point_scale(mh);
-    dense_layer<8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 7));
+    dense_h3<RING, 8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 7));
     finish_tiles<8, false>(acc, sc.inv, const_at(vp::S_BF), h);
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
@@ -198,8 +197,8 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
         sc = point_scale(fmaxf(mf, md));
     }
     f32x16 hr[4];
-    dense_layer<8, 4, SAVE, true>(wst, acc, sc.s, hr, rows_of(vw::FEAT));
-    dense_layer<1, 4, SAVE>(wst, de, sc.s, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
+    dense_h3<RING, 8, 4, SAVE, true>(wst, acc, sc.s, hr, rows_of(vw::FEAT));
+    dense_h3<RING, 1, 4, SAVE>(wst, de, sc.s, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
     finish_tiles<4, true>(hr, sc.inv, const_at(vp::S_B1), h);
     if (SAVE) {
         publish_max(abs_max<4>(hr), vw::SLOT_HR);
@@ -223,13 +222,14 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
                                                                const float* __restrict__ sigma,
                                                                const float* __restrict__ ws, float* __restrict__ ws2,
                                                                unsigned* __restrict__ amax) {
+    constexpr int RING = BWD_RING;
     __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
     TileIdx ix;
     tile_index(P, ix);
     const int lane = ix.lane, h = ix.h;
     WeightStream wst{lds, 0, ix.wave, lane};
-    const TileBuf tb = tile_buf(lds + STREAM_LDS_FLOATS + ix.wave * TILE_LDS_FLOATS, lane);
-    const unsigned consts = copy_consts(lds, pk, ix.wave, lane);
+    const TileBuf tb = tile_buf(lds + tiles_lds_off(RING) + ix.wave * TILE_LDS_FLOATS, lane);
+    const unsigned consts = copy_consts(lds + const_lds_off(RING), pk, ix.wave, lane);
     auto const_at = [&](int packed_off) { return consts + 4 * (packed_off - vp::S_BIAS); };
     // the ReLU bits of this wave's tile, [layer][lane] 16 bytes each, also through LDS (a load from memory in the
     // middle of the chain would wait for every weight copy in flight)
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
         asm volatile("" : "+v"(w));
         return make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
     };
-    h3_prime(wst, pk + vp::B_RGB0, pk + vp::S_BIAS);
+    h3_prime<RING>(wst, pk + vp::B_RGB0, pk + vp::S_BIAS);
     float dpre[3], dps = 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -302,13 +302,13 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
     float m = abs_max<4>(dyr);
     publish_max(m, 9);
     PointScale sc = point_scale(m);
-    dense_layer<4, 8, true, true>(wst, dyr, sc.s, a,
+    dense_h3<RING, 4, 8, true, true>(wst, dyr, sc.s, a,
                                   tile_save(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128));   // d feat
     scale_tiles<8>(a, sc.inv);
     m = abs_max<8>(a);
     publish_max(m, 8);
     sc = point_scale(m);
-    dense_layer<8, 8, true, true>(wst, a, sc.s, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
+    dense_h3<RING, 8, 8, true, true>(wst, a, sc.s, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
     {
         const unsigned wsig = const_at(vp::S_WS) + 16 * h;
         static_for<0, 2>([&](auto chalf) {                                 // ... plus the density head
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
         m = abs_max<8>(b);
         publish_max(m, l);
         sc = point_scale(m);
-        dense_layer<8, 8, true, true>(wst, b, sc.s, a, rows_of(vw::DY + l * 256));
+        dense_h3<RING, 8, 8, true, true>(wst, b, sc.s, a, rows_of(vw::DY + l * 256));
         scale_tiles<8>(a, sc.inv);
         apply_bits<8>(a, bits_of(l - 1));
 #pragma unroll

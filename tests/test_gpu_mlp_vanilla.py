@@ -162,3 +162,49 @@ def test_full_fine_pass_size_properties(dev):
         s = (gl.double() + gh.double())
         err = float((ga.double() - s).norm())
         assert err <= 1e-5 * float(s.norm()) or err <= 2e-7 * P * ga.numel() ** 0.5, (k, err, float(s.norm()))
+
+
+@pytest.mark.parametrize("wscale,gscale", [(8.0, 1.0), (1e-3, 1.0), (1.0, 2.0 ** -40), (1.0, 2.0 ** 30), (3.0, 1e-12)])
+def test_operand_scaling_extremes(dev, wscale, gscale):
+    """The MFMA operands are f16 pieces of power-of-two-scaled values: activations that grow to 1e7 or shrink to
+    1e-24 through the layers (weights x 8, x 1e-3) and output gradients of 1e-12 or 1e9 must come through like
+    ordinary ones -- outputs and every parameter gradient against the float64-accumulating oracle."""
+    from nerf_amd.models.NeRF import NeRF
+    P = 600
+    torch.manual_seed(21)
+    ref = O.NeRFOracle()
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if k.endswith("weight") and ("layers" in k or "feature" in k):
+                p.mul_(wscale)
+    m = NeRF()
+    m.load_state_dict(ref.state_dict())
+    m = m.to(dev)
+    gen = torch.Generator().manual_seed(22)
+    x = torch.rand(P, 3, generator=gen) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(P, 3, generator=gen), dim=-1)
+    a = torch.randn(P, 3, generator=gen) * gscale
+    b = torch.randn(P, 1, generator=gen) * gscale
+    rgb_o, sig_o = ref(x, d)
+    ((rgb_o * a).sum() + (sig_o * b).sum()).backward()
+    rgb, sig = m(x.to(dev), d.to(dev))
+    ((rgb * a.to(dev)).sum() + (sig * b.to(dev)).sum()).backward()
+    assert torch.isfinite(rgb).all() and torch.isfinite(sig).all()
+    assert float((rgb.detach().cpu() - rgb_o.detach()).abs().max()) < 2e-5
+    assert rel_err(sig.detach().cpu(), sig_o.detach()) < 1e-5
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert torch.isfinite(p.grad).all(), k
+        err = float((p.grad.cpu().double() - q.grad.double()).norm())
+        assert err <= 1e-4 * float(q.grad.double().norm()) + 1e-30, (k, err, float(q.grad.double().norm()))
+
+
+def test_zero_output_gradient_gives_zero_gradients(dev):
+    from nerf_amd.models.NeRF import NeRF
+    torch.manual_seed(5)
+    m = NeRF().to(dev)
+    x = (torch.rand(300, 3) * 4 - 2).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(300, 3), dim=-1).to(dev)
+    rgb, sig = m(x, d)
+    ((rgb * 0.0).sum() + (sig * 0.0).sum()).backward()
+    for k, p in m.named_parameters():
+        assert float(p.grad.abs().max()) == 0.0, k
