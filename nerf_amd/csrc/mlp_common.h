@@ -129,6 +129,9 @@ struct TileSave {
     TileBuf tb;
     float* rows0;   // row 0 of the tile's 32 rows, already offset by this lane's (row, col)
     int ld;
+    uint4* relu_bits_out = nullptr;   // PRE_RELU: one bit per input neuron (1 = positive) goes here, in relu_bits() order
+    uint4 bits = {0u, 0u, 0u, 0u};    // PRE_MASK: the inputs to keep, in the same order
+    float out_scale = 1.0f;           // PRE_OUTSCALE: the rows are written multiplied by this
 };
 __device__ __forceinline__ TileSave tile_save(const TileBuf& tb, float* tile_rows0, int ld = 256) {
     return TileSave{tb, tile_rows0 + (size_t)tb.row * ld + tb.col, ld};
@@ -270,6 +273,16 @@ __device__ __forceinline__ float abs_max(const f32x16 (&a)[NT], float m = 0.0f) 
     return m;
 }
 
+// The same over the positive parts (the largest output of a ReLU that has not been applied yet).
+template <int NT>
+__device__ __forceinline__ float pos_max(const f32x16 (&a)[NT], float m = 0.0f) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(a[t][r], a[t][r + 1]), m);
+    return m;
+}
+
 // The weight stream of the f16 x 3 layers.  The packed layers of a kernel lie in memory in the order they are
 // used and every chunk is 16 KiB (a k-step of 8 out tiles, or two k-steps of 4), so the stream is one linear
 // run of chunks through RING rotating LDS buffers: while chunk c is multiplied, chunk c+1 has landed, chunks
@@ -311,38 +324,80 @@ constexpr int h3_stores(int k0, int k1) {
     return n;
 }
 
+// What a layer does to its input tiles on their way in -- in place, as part of the operand split, i.e. in the
+// shadow of the MFMAs instead of in the previous layer's epilogue:
+//   PRE_RELU      in = max(in, 0); with DRAIN the ReLU bits are recorded and stored to sv.relu_bits_out
+//   PRE_MASK      in = sv.bits ? in : 0
+//   PRE_OUTSCALE  the rows DRAIN writes are in * sv.out_scale (the tiles themselves stay as they are)
+constexpr int PRE_NONE = 0, PRE_RELU = 1, PRE_MASK = 2, PRE_OUTSCALE = 4;
+
 // acc[ot] (+)= W_tile(ot, kt) * (scale * in[kt]), the layer's weights being the next KT * OT / 4 chunks of the
 // stream.  A chunk is two groups of 12 MFMAs (4 out tiles x 3 terms): the two halves of a k-step (OT = 8) or two
 // k-steps (OT = 4); one barrier per chunk, between its groups.
 // ZERO: the accumulators start from zero (their contents on entry are ignored).
 // DRAIN: also write the input tiles (unscaled) to sv.rows0, tile t during k-steps 2t and 2t+1.
-template <int RING, int KT, int OT, bool DRAIN = false, bool ZERO = false>
-__device__ __forceinline__ void dense_h3(WeightStream& ws, const f32x16 (&in)[KT], float scale, f32x16 (&acc)[OT],
+template <int RING, int KT, int OT, bool DRAIN = false, bool ZERO = false, int PRE = PRE_NONE>
+__device__ __forceinline__ void dense_h3(WeightStream& ws, f32x16 (&in)[KT], float scale, f32x16 (&acc)[OT],
                                          TileSave sv = TileSave{TileBuf{0, 0, 0, 0}, nullptr, 0}) {
     static_assert(OT == 4 || OT == 8, "out tiles are processed four at a time, two groups per chunk");
     constexpr int S = 2 * KT, G = OT / 4, NCH = S * G / 2;
-    constexpr int NM = 12, NSPLIT = 6, SLOTS = NM * G;   // MFMAs per group; steps of the operand split; MFMAs per k-step
+    constexpr int NM = 12, NSPLIT = 11, SLOTS = NM * G;   // MFMAs per group; steps of the operand split; MFMAs per k-step
     constexpr int RMASK = RING - 1;
     static_assert(RING >= 4 && (RING & RMASK) == 0, "the ring is indexed with a mask");
+    constexpr bool RELU = (PRE & PRE_RELU) != 0, MASK = (PRE & PRE_MASK) != 0, OUTSCALE = (PRE & PRE_OUTSCALE) != 0;
+    constexpr bool BITS_OUT = RELU && DRAIN;
+    static_assert(!(RELU && MASK) && KT <= 8, "one input transform; 8 tiles of ReLU bits fit 128 bits");
     f16x8 a[2][8];                   // operands of a group of 4 out tiles (tile*2 + piece), double-buffered
     u32x4 b[3];                      // this k-step's B pieces (h, h'', l); the next one's are built in nh, nh2, nl
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};   // two row blocks on their way out
-    const f32x2 scale2 = {scale, scale};
     u32x4 nh, nh2, nl;
-    f32x2 xs[4];
     float sr0[4], sr1[4];
-    // The split of the next k-step in six steps of four independent instructions, one step every few MFMAs: an
-    // instruction issued right behind the one it depends on waits ~9 clocks with the MFMA behind it.
+    unsigned mw[4] = {0u, 0u, 0u, 0u};   // BITS_OUT: the ReLU bits so far
+    unsigned mb[8], mp[4], mq[2], mf = 0u;
+    int kp[8];
+    const unsigned keep_words[4] = {sv.bits.x, sv.bits.y, sv.bits.z, sv.bits.w};
+    // The split of the next k-step in eleven steps of at most six independent instructions, one step every few
+    // MFMAs: an instruction issued right behind the one it depends on waits ~9 clocks with the MFMA behind it, and
+    // more than five or six between two MFMAs no longer hide behind the first.  (Plain multiplies: a packed fp32
+    // instruction beside an MFMA costs more than the two it replaces.)  Value j of the k-step is register 8u + j of
+    // tile t (k-step 2t + u), bit 16 (t & 1) + 8u + j of word t / 2 of the ReLU bits.
+    float xs[8];
     auto split_chunk = [&](auto cs, auto ck) {
-        constexpr int s = decltype(cs)::value, k = decltype(ck)::value;
+        constexpr int s = decltype(cs)::value, k = decltype(ck)::value, t = s / 2, r0 = 8 * (s % 2), pos = 16 * (t & 1) + r0;
+        if constexpr (k < 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if constexpr (k == 0) xs[i] = f32x2{in[s / 2][8 * (s % 2) + 2 * i], in[s / 2][8 * (s % 2) + 2 * i + 1]} * scale2;
-            else if constexpr (k == 1) nh[i] = cvt_pk_f16(xs[i][0], xs[i][1]);
-            else if constexpr (k == 2) sr0[i] = sub_f16<0>(xs[i][0], nh[i]);
-            else if constexpr (k == 3) sr1[i] = sub_f16<1>(xs[i][1], nh[i]);
-            else if constexpr (k == 4) nl[i] = cvt_pk_f16(sr0[i], sr1[i]);
-            else nh2[i] = pk_f16_down11(nh[i]);
+            for (int j = 4 * k; j < 4 * k + 4; ++j) {
+                if constexpr (RELU) in[t][r0 + j] = fmaxf(in[t][r0 + j], 0.0f);
+                if constexpr (MASK) kp[j] = __builtin_amdgcn_sbfe((int)keep_words[t >> 1], pos + j, 1);   // 0 or -1
+            }
+        } else if constexpr (k < 4) {
+#pragma unroll
+            for (int j = 4 * (k - 2); j < 4 * (k - 2) + 4; ++j) {
+                if constexpr (BITS_OUT) mb[j] = min(__float_as_uint(in[t][r0 + j]), 1u);
+                if constexpr (MASK) in[t][r0 + j] = __uint_as_float(__float_as_uint(in[t][r0 + j]) & (unsigned)kp[j]);
+            }
+        } else if constexpr (k < 6) {
+#pragma unroll
+            for (int j = 4 * (k - 4); j < 4 * (k - 4) + 4; ++j) xs[j] = in[t][r0 + j] * scale;
+            if constexpr (BITS_OUT) {
+                mp[2 * (k - 4)] = (mb[4 * (k - 4) + 1] << 1) | mb[4 * (k - 4)];
+                mp[2 * (k - 4) + 1] = (mb[4 * (k - 4) + 3] << 1) | mb[4 * (k - 4) + 2];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (k == 6) nh[i] = cvt_pk_f16(xs[2 * i], xs[2 * i + 1]);
+                else if constexpr (k == 7) sr0[i] = sub_f16<0>(xs[2 * i], nh[i]);
+                else if constexpr (k == 8) sr1[i] = sub_f16<1>(xs[2 * i + 1], nh[i]);
+                else if constexpr (k == 9) nl[i] = cvt_pk_f16(sr0[i], sr1[i]);
+                else nh2[i] = pk_f16_down11(nh[i]);
+            }
+            if constexpr (BITS_OUT && k == 6) {
+                mq[0] = (mp[1] << 2) | mp[0];
+                mq[1] = (mp[3] << 2) | mp[2];
+            }
+            if constexpr (BITS_OUT && k == 7) mf = (mq[1] << 4) | mq[0];
+            if constexpr (BITS_OUT && k == 8) mw[t >> 1] = (mf << pos) | mw[t >> 1];
         }
     };
     auto take_split = [&]() {
@@ -431,7 +486,11 @@ __device__ __forceinline__ void dense_h3(WeightStream& ws, const f32x16 (&in)[KT
                 // an input tile goes into the transposition buffer and two of its row blocks come back out
                 if constexpr (DRAIN && g == 0 && s % 2 == 0 && m >= 7 && m <= 10) {
                     constexpr int qq = m - 7;
-                    lds_write4<32 * qq>(sv.tb.wr, f32x4{in[s / 2][4 * qq], in[s / 2][4 * qq + 1], in[s / 2][4 * qq + 2], in[s / 2][4 * qq + 3]});
+                    if constexpr (OUTSCALE)
+                        lds_write4<32 * qq>(sv.tb.wr, f32x4{in[s / 2][4 * qq] * sv.out_scale, in[s / 2][4 * qq + 1] * sv.out_scale,
+                                                            in[s / 2][4 * qq + 2] * sv.out_scale, in[s / 2][4 * qq + 3] * sv.out_scale});
+                    else
+                        lds_write4<32 * qq>(sv.tb.wr, f32x4{in[s / 2][4 * qq], in[s / 2][4 * qq + 1], in[s / 2][4 * qq + 2], in[s / 2][4 * qq + 3]});
                 }
                 if constexpr (DRAIN && g == G - 1 && m == 11) {
                     constexpr int k0 = 2 * (s % 2);
@@ -458,6 +517,7 @@ __device__ __forceinline__ void dense_h3(WeightStream& ws, const f32x16 (&in)[KT
         __builtin_nontemporal_store(d0, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)16 * sv.ld + 32 * t));
         __builtin_nontemporal_store(d1, reinterpret_cast<f32x4*>(sv.rows0 + (size_t)24 * sv.ld + 32 * t));
     }
+    if constexpr (BITS_OUT) *sv.relu_bits_out = make_uint4(mw[0], mw[1], mw[2], mw[3]);
     ws.g3 = (ws.g3 + NCH) & RMASK;
 }
 

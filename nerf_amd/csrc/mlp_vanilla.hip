@@ -147,16 +147,19 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
     ws_ready();
 
     f32x16 hc[8], acc[8];
-    // Training: the activations of layer l are the input tiles of layer l+1, which writes
-    // them out row by row underneath its MFMAs (see TileSave).
-    auto rows_of = [&](int section) { return tile_save(tb, ws + ix.P32 * section + ix.tile * 32 * 256); };
-    float mh = 0.0f;   // largest |activation| of this lane's half of the current layer
-    auto finish_layer = [&](int l, float inv) {
-        finish_tiles<8, true>(acc, inv, const_at(vp::S_BIAS + 256 * l), h);
+    // Training: the activations of layer l are the input tiles of layer l+1, which applies the ReLU to them and
+    // writes them out row by row, and their ReLU bits, underneath its MFMAs (see TileSave, PRE_RELU).
+    auto rows_of = [&](int section, int bits_layer) {
+        TileSave sv = tile_save(tb, ws + ix.P32 * section + ix.tile * 32 * 256);
+        sv.relu_bits_out = mask_out + bits_layer * 64;
+        return sv;
+    };
+    float mh = 0.0f;   // largest activation of this lane's half of the current layer
+    auto finish_layer = [&](int l, float inv) {   // bias; the ReLU is left to the next layer
+        finish_tiles<8, false>(acc, inv, const_at(vp::S_BIAS + 256 * l), h);
 #pragma unroll
         for (int t = 0; t < 8; ++t) hc[t] = acc[t];
-        if (SAVE) mask_out[l * 64] = relu_bits<8>(hc);
-        mh = abs_max<8>(hc);
+        mh = pos_max<8>(hc);
         publish_max(mh, vw::SLOT_H + l);
     };
     // layer 0
@@ -166,27 +169,27 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
         sc = point_scale(mh);
-        dense_h3<RING, 8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1)));
+        dense_h3<RING, 8, 8, SAVE, true, PRE_RELU>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1), l - 1));
         finish_layer(l, sc.inv);
     }
     // skip connection: the layer-4 input is [x_enc | h] (either column order, see the packing), one scale for both
     sc = point_scale(fmaxf(mx, mh));
     dense_h3<RING, 2, 8, false, true>(wst, xe, sc.s, acc);
-    dense_h3<RING, 8, 8, SAVE>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 3));
+    dense_h3<RING, 8, 8, SAVE, false, PRE_RELU>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 3, 3));
     finish_layer(4, sc.inv);
 #pragma unroll 1
     for (int l = 5; l < 8; ++l) {
         sc = point_scale(mh);
-        dense_h3<RING, 8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1)));
+        dense_h3<RING, 8, 8, SAVE, true, PRE_RELU>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * (l - 1), l - 1));
         finish_layer(l, sc.inv);
     }
+    // feature layer (no activation)      (NeRF.py:95); it also applies layer 7's ReLU
+    sc = point_scale(mh);
+    dense_h3<RING, 8, 8, SAVE, true, PRE_RELU>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 7, 7));
+    finish_tiles<8, false>(acc, sc.inv, const_at(vp::S_BF), h);
     // density head: softplus(w.h + b)   (NeRF.py:90)
     const float sp = dot_rows_lds<8>(hc, const_at(vp::S_WS), h) + lds_read1(const_at(vp::S_BS));
     if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(sp);
-    // feature layer (no activation)      (NeRF.py:95)
-    sc = point_scale(mh);
-    dense_h3<RING, 8, 8, SAVE, true>(wst, hc, sc.s, acc, rows_of(vw::H + 256 * 7));
-    finish_tiles<8, false>(acc, sc.inv, const_at(vp::S_BF), h);
     // colour head: sigmoid(W2 relu(W1 [feat | pe(dir)] + b1) + b2)   (NeRF.py:94-97)
     f32x16 de[1];
     pe_tiles<1, 4>(de, dir0, dir1, dir2, h);
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void vanilla_fwd_kernel(const float* __restric
         sc = point_scale(fmaxf(mf, md));
     }
     f32x16 hr[4];
-    dense_h3<RING, 8, 4, SAVE, true>(wst, acc, sc.s, hr, rows_of(vw::FEAT));
+    dense_h3<RING, 8, 4, SAVE, true>(wst, acc, sc.s, hr, tile_save(tb, ws + ix.P32 * vw::FEAT + ix.tile * 32 * 256));
     dense_h3<RING, 1, 4, SAVE>(wst, de, sc.s, hr, tile_save(tb, ws + ix.P32 * vw::DE + ix.tile * 32 * 32, 32));
     finish_tiles<4, true>(hr, sc.inv, const_at(vp::S_B1), h);
     if (SAVE) {
@@ -294,21 +297,31 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
                 }
         });
     }
-    apply_bits<4>(dyr, bits_of(8));
 
-    // Each 256-wide gradient tile set is the input of the next layer down, which writes it out underneath its MFMAs.
-    auto rows_of = [&](int section) { return tile_save(tb, ws2 + ix.P32 * section + ix.tile * 32 * 256); };
+    // Each 256-wide gradient tile set is the input of the next layer down, which applies the ReLU bits to it and
+    // writes it out underneath its MFMAs.  The accumulators are not rescaled in between: `carry` is the factor
+    // that turns the current tiles into gradients, folded into the next layer's operand scale and row stores.
+    // (The published maxima are those before the ReLU bits: upper bounds.)
+    auto rows_of = [&](int section, int bits_layer, float carry) {
+        TileSave sv = tile_save(tb, ws2 + ix.P32 * section + ix.tile * 32 * 256);
+        if (bits_layer >= 0) sv.bits = bits_of(bits_layer);
+        sv.out_scale = carry;
+        return sv;
+    };
     f32x16 a[8], b[8];
     float m = abs_max<4>(dyr);
     publish_max(m, 9);
     PointScale sc = point_scale(m);
-    dense_h3<RING, 4, 8, true, true>(wst, dyr, sc.s, a,
-                                  tile_save(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128));   // d feat
-    scale_tiles<8>(a, sc.inv);
-    m = abs_max<8>(a);
+    {
+        TileSave sv = tile_save(tb, ws2 + ix.P32 * vw::DYR + ix.tile * 32 * 128, 128);
+        sv.bits = bits_of(8);
+        dense_h3<RING, 4, 8, true, true, PRE_MASK>(wst, dyr, sc.s, a, sv);   // d feat (times sc.s)
+    }
+    float carry = sc.inv;
+    m = abs_max<8>(a) * carry;
     publish_max(m, 8);
     sc = point_scale(m);
-    dense_h3<RING, 8, 8, true, true>(wst, a, sc.s, b, rows_of(vw::DFEAT));   // d h7 through the feature layer ...
+    dense_h3<RING, 8, 8, true, true, PRE_OUTSCALE>(wst, a, sc.s * carry, b, rows_of(vw::DFEAT, -1, carry));   // d h7 through the feature layer ...
     {
         const unsigned wsig = const_at(vp::S_WS) + 16 * h;
         static_for<0, 2>([&](auto chalf) {                                 // ... plus the density head
@@ -331,18 +344,19 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
                 }
         });
     }
-    apply_bits<8>(b, bits_of(7));
+    carry = 1.0f;
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {                 // d h_{l-1} = W_l^T d y_l (h columns only at l = 4)
-        m = abs_max<8>(b);
+        m = abs_max<8>(b) * carry;
         publish_max(m, l);
         sc = point_scale(m);
-        dense_h3<RING, 8, 8, true, true>(wst, b, sc.s, a, rows_of(vw::DY + l * 256));
-        scale_tiles<8>(a, sc.inv);
-        apply_bits<8>(a, bits_of(l - 1));
+        dense_h3<RING, 8, 8, true, true, PRE_MASK | PRE_OUTSCALE>(wst, b, sc.s * carry, a, rows_of(vw::DY + l * 256, l, carry));
+        carry = sc.inv;
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[t] = a[t];
     }
+    apply_bits<8>(b, bits_of(0));
+    scale_tiles<8>(b, carry);
     publish_max(abs_max<8>(b), 0);
     save_tiles<8>(tb, ws2 + ix.P32 * vw::DY + ix.tile * 32 * 256, 256, b);
 }
