@@ -691,9 +691,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     }
 }
 
-// Relative time per point of a workgroup of each shape (measured for the first three; the
-// narrow shapes run below their MFMA count): the cost model of the slab split.
-static const int kShapeCost[6] = {32, 24, 17, 8, 8, 8};
+// Relative time per point of a workgroup of each shape (the first three from a sweep of the ratios at 786,432
+// points: 3.62 ms with 32:24:17, 3.21 ms with these; the narrow shapes run below their MFMA count): the cost model
+// of the slab split.
+static const int kShapeCost[6] = {24, 19, 22, 8, 8, 8};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     // A workgroup takes a whole CU (512 registers per lane), so the grid is sized
