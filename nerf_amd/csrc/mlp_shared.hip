@@ -316,9 +316,10 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
 }
 
 // ------------------------------------------------------- wgrad, bf16 x 6 ----
-// The same contraction on bf16 x 6 MFMAs (see dense_x6 in mlp_common.h): K = 16 points per
-// MFMA, lane (i, hb) holds points 8hb..8hb+7 of column i of dY (A operand) or of X (B
-// operand).  Both operands arrive as fp32 rows in LDS, so every wave splits what it
+// The same contraction on bf16 x 6 MFMAs (every fp32 operand split into three bf16 numbers v = h + m + l, a
+// product being the six bf16 MFMAs that matter: hh, hm, mh, mm, hl, lh; no scaling needed, bf16 has the exponent
+// range of fp32): K = 16 points per MFMA, lane (i, hb) holds points 8hb..8hb+7 of column i of dY (A operand) or of
+// X (B operand).  Both operands arrive as fp32 rows in LDS, so every wave splits what it
 // reads: 8 ds_read_b32 and ~50 VALU instructions per operand tile, placed among the MFMAs
 // of the previous work item so that they run in the MFMAs' shadow.
 //

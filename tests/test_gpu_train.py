@@ -48,7 +48,7 @@ def test_hierarchical_render_step_matches_oracle(dev):
     # switches between two float32 implementations) moves a trunk gradient by ~1e-3.
     # Measured against a float64 evaluation of the same pipeline, over several seeds: the
     # float32 CPU path 1.5e-3, the exact-f32 MFMA kernels 3e-4 / 1.9e-3 / 3e-2, the
-    # bf16x6 kernels 1.5e-3 / 1.9e-3 / 3e-2 (maximum over parameters; medians 1e-6..5e-5),
+    # split-operand MFMA kernels 1.5e-3 / 1.9e-3 / 3e-2 (maximum over parameters; medians 1e-6..5e-5),
     # and the CPU result differs between CPUs.  The 1e-3 contract is therefore held where
     # it is well-posed -- per kernel, with dense upstream gradients (test_gpu_mlp_vanilla,
     # 1e-4) -- and the whole render is held to 5e-3 against both the float64 evaluation at
