@@ -521,20 +521,6 @@ __device__ __forceinline__ void dense_h3(WeightStream& ws, f32x16 (&in)[KT], flo
     ws.g3 = (ws.g3 + NCH) & RMASK;
 }
 
-// bf16 x 3 splits (v = h + m + l, 8 bits each) of the weight-gradient kernels that split per wave
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 hh = (__bf16)v[i];
-        const float r1 = v[i] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        h[i] = hh;
-        m[i] = mm;
-        l[i] = (__bf16)(r1 - (float)mm);
-    }
-}
-
 // dot_rows() below with the vector in LDS (byte address v_lds): a vector-memory load at that point would wait
 // for every weight copy in flight.  Half of the tiles per round trip.
 template <int NT>

@@ -1,5 +1,5 @@
 // Kernels shared by the fused MLPs: weight packing, the weight-gradient GEMMs
-// (contraction over points on split-f16, split-bf16 or exact-f32 MFMAs) and the small-head gradients.
+// (contraction over points on split-f16 or exact-f32 MFMAs) and the small-head gradients.
 #include "mlp_common.h"
 
 namespace nerf {
@@ -315,149 +315,9 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
     wgrad_finish<NTW, KT, KT2>(pt, acc, bsum, n0, i, s);
 }
 
-// ------------------------------------------------------- wgrad, bf16 x 6 ----
-// The same contraction on bf16 x 6 MFMAs (every fp32 operand split into three bf16 numbers v = h + m + l, a
-// product being the six bf16 MFMAs that matter: hh, hm, mh, mm, hl, lh; no scaling needed, bf16 has the exponent
-// range of fp32): K = 16 points per MFMA, lane (i, hb) holds points 8hb..8hb+7 of column i of dY (A operand) or of
-// X (B operand).  Both operands arrive as fp32 rows in LDS, so every wave splits what it
-// reads: 8 ds_read_b32 and ~50 VALU instructions per operand tile, placed among the MFMAs
-// of the previous work item so that they run in the MFMAs' shadow.
-//
-// A chunk (32 points) is 2 k-steps u of J = KTT/GROUP work items, an item being GROUP B
-// tiles with 6*NTW*GROUP MFMAs, ordered so that an accumulator recurs every NTW*GROUP >= 3
-// MFMAs (a dependent 8-pass MFMA issued sooner stalls).  In the region of item c: wait for
-// the raw values of item c+1, request those of item c+2, split item c+1 (and, in region 0,
-// the A tiles of k-step 1) between the MFMAs of item c.  The A tiles of k-step 0 and item 0
-// are prepared right after the chunk's barrier, the only part that runs without MFMAs; the
-// per-chunk state stays local to the chunk (carried across the chunk loop it costs twice
-// the registers, and a spilled operand of an asm load is spilled before it has arrived).
-__device__ __forceinline__ void split_pair(const float (&v)[8], int e, bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i / 2 == e) {
-            const __bf16 hh = (__bf16)v[i];
-            const float r1 = v[i] - (float)hh;
-            const __bf16 mm = (__bf16)r1;
-            h[i] = hh;
-            m[i] = mm;
-            l[i] = (__bf16)(r1 - (float)mm);
-        }
-    }
-}
-
-template <int NTW, int KT, int KT2, int GROUP>
-__device__ __forceinline__ void wgrad_part_x6(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
-                                              float* lds) {
-    using S = WgradShape<NTW, KT, KT2, 4>;
-    constexpr int KTT = KT + KT2, J = KTT / GROUP, ITEMS = 2 * J, NM = 6 * NTW * GROUP;
-    static_assert(KTT % GROUP == 0 && NM >= 4 * (GROUP + NTW), "item shape");
-    const int i = lane & 31, s = lane >> 5;
-    const int n0 = wave * NTW * 32;
-    f32x16 acc[NTW][KTT];
-    float bsum[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        bsum[nt] = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < KTT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][kt][r] = 0.0f;
-    }
-    const WgradSrc<NTW, KT, KT2, 4> src(pt, wave, lane);
-    constexpr int PW = WgradSrc<NTW, KT, KT2, 4>::GROUPS;
-    src.template stage<0, PW>(p_begin, lds);
-    int cur = 0;
-#pragma unroll 1
-    for (long long p = p_begin; p < p_end; p += WG_CH) {
-        __syncthreads();   // this chunk has landed for every wave, and every wave is done with the other buffer
-        const bool more = p + WG_CH < p_end;
-        const float* buf = lds + cur * S::CHUNK;
-        float* nxt = lds + (cur ^ 1) * S::CHUNK;
-        const unsigned r_dy = lds_addr(buf + S::DY_OFF + 8 * s * S::N + n0 + i);
-        const unsigned r_x = lds_addr(buf + S::X_OFF + 8 * s * S::XW + i);
-        const unsigned r_x2 = lds_addr(buf + S::X2_OFF + 8 * s * S::X2W + i);
-        float raw[2][GROUP][8], raw_a[2][NTW][8];
-        bf16x8 as[2][NTW][3], bs[2][GROUP][3];
-        auto load_item = [&](auto cc, float (&o)[GROUP][8]) {   // points 16u + 8s + q of X columns 32kt + i
-            constexpr int c = decltype(cc)::value, u = c / J;
-            static_for<0, GROUP>([&](auto cg) {
-                constexpr int kt = GROUP * (c % J) + decltype(cg)::value;
-                static_for<0, 8>([&](auto cq) {
-                    constexpr int q = decltype(cq)::value;
-                    if constexpr (kt < KT) o[cg][q] = lds_read<((16 * u + q) * S::XW + 32 * kt) * 4>(r_x);
-                    else o[cg][q] = lds_read<((16 * u + q) * S::X2W + 32 * (kt - KT)) * 4>(r_x2);
-                });
-            });
-        };
-        auto load_a = [&](auto cu, float (&o)[NTW][8]) {
-            constexpr int u = decltype(cu)::value;
-            static_for<0, NTW>([&](auto cnt) {
-                static_for<0, 8>([&](auto cq) {
-                    o[cnt][cq] = lds_read<((16 * u + decltype(cq)::value) * S::N + 32 * decltype(cnt)::value) * 4>(r_dy);
-                });
-            });
-        };
-        auto tie8 = [&](float (&o)[8]) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(o[q]));
-        };
-        // after the barrier: requests for both k-steps' A tiles and item 0; half of the next chunk's copies
-        load_a(std::integral_constant<int, 0>{}, raw_a[0]);
-        load_item(std::integral_constant<int, 0>{}, raw[0]);
-        load_a(std::integral_constant<int, 1>{}, raw_a[1]);
-        if (more) src.template stage<0, PW / 2>(p + WG_CH, nxt);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            tie8(raw_a[0][nt]);
-            tie8(raw_a[1][nt]);
-            split3(raw_a[0][nt], as[0][nt][0], as[0][nt][1], as[0][nt][2]);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) bsum[nt] += raw_a[0][nt][q] + raw_a[1][nt][q];
-        }
-#pragma unroll
-        for (int g = 0; g < GROUP; ++g) {
-            tie8(raw[0][g]);
-            split3(raw[0][g], bs[0][g][0], bs[0][g][1], bs[0][g][2]);
-        }
-        if constexpr (ITEMS > 1) load_item(std::integral_constant<int, 1>{}, raw[1]);
-        static_for<0, ITEMS>([&](auto cc) {
-            constexpr int c = decltype(cc)::value, u = c / J, k0 = GROUP * (c % J);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (c + 1 < ITEMS) {
-#pragma unroll
-                for (int g = 0; g < GROUP; ++g) tie8(raw[(c + 1) % 2][g]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (c + 2 < ITEMS) load_item(std::integral_constant<int, c + 2>{}, raw[c % 2]);
-            if constexpr (c == 0) {
-                if (more) src.template stage<PW / 2, PW>(p + WG_CH, nxt);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // MFMAs of item c, term-major; between them the splits of item c+1 and, in region 0, of the A tiles of k-step 1
-            static_for<0, NM>([&](auto cm) {
-                constexpr int m = decltype(cm)::value, term = m / (NTW * GROUP), nt = (m / GROUP) % NTW, g = m % GROUP;
-                constexpr int ai = term == 0 ? 2 : term == 1 ? 0 : term == 2 ? 1 : term == 3 ? 1 : 0;
-                constexpr int bi = term == 0 ? 0 : term == 1 ? 2 : term == 2 ? 1 : term == 3 ? 0 : term == 4 ? 1 : 0;
-                acc[nt][k0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[u][nt][ai], bs[c % 2][g][bi], acc[nt][k0 + g], 0, 0, 0);
-                asm volatile("" : "+a"(acc[nt][k0 + g]));
-                if constexpr (c + 1 < ITEMS && m < 4 * GROUP)
-                    split_pair(raw[(c + 1) % 2][m / 4], m % 4, bs[(c + 1) % 2][m / 4][0], bs[(c + 1) % 2][m / 4][1], bs[(c + 1) % 2][m / 4][2]);
-                if constexpr (c == 0 && m >= 4 * GROUP && m < 4 * (GROUP + NTW)) {
-                    constexpr int e = m - 4 * GROUP, nta = e / 4;
-                    split_pair(raw_a[1][nta], e % 4, as[1][nta][0], as[1][nta][1], as[1][nta][2]);
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        cur ^= 1;
-    }
-    wgrad_finish<NTW, KT, KT2>(pt, acc, bsum, n0, i, s);
-}
-
 // ---- The same product on split-f16 MFMAs, the operands split once per workgroup ---------------------
-// Above, every wave splits each X tile it multiplies with: four times the work per workgroup.  Here a k-step
+// K = 16 points per MFMA: lane (i, hb) holds points 8hb..8hb+7 of column i of dY (A operand) or of X (B operand).
+// If every wave split each X tile it multiplies with, a workgroup would do that work four times.  Here a k-step
 // (16 points) of dY and X is loaded into registers once, split there into two f16 pieces (see dense_h3 in
 // mlp_common.h: v = h + l, three MFMAs per product) and stored to LDS as ready operands:
 // [tile][h, l][operand lane][8 points], which every wave then reads with one 16-byte load per operand.
@@ -669,7 +529,7 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
 }
 
 // shape ids (NTW,KT,KT2,NW): 0 = <2,8,0,4>  1 = <1,8,1,4>  2 = <2,2,0,4>   (a 320-register <2,8,2> tile set does
-// not allocate without spills);  small layers of the hash-grid model: 3 = <1,1,0,2>  4 = <1,2,0,1>  5 = <1,1,1,2>
+// not allocate without spills; the first three on split-f16 MFMAs, the rest on the exact-f32 MFMA);  small layers of the hash-grid model: 3 = <1,1,0,2>  4 = <1,2,0,1>  5 = <1,1,1,2>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
     int pi = 0;
@@ -685,17 +545,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     switch (pt.shape) {
         case 0: wgrad_part_pk<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 1: wgrad_part_pk<1, 8, 1, 3>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        case 2: wgrad_part_x6<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;   // 24 MFMAs per k-step cannot hide the loads of the shared split
+        case 2: wgrad_part_pk<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 3: wgrad_part<1, 1, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 4: wgrad_part<1, 2, 0, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         default: wgrad_part<1, 1, 1, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
     }
 }
 
-// Relative time per point of a workgroup of each shape (the first three from a sweep of the ratios at 786,432
-// points: 3.62 ms with 32:24:17, 3.21 ms with these; the narrow shapes run below their MFMA count): the cost model
-// of the slab split.
-static const int kShapeCost[6] = {24, 19, 22, 8, 8, 8};
+// Relative time per point of a workgroup of each shape (the first three from sweeps of the ratios at 786,432
+// points: 3.62 ms with 32:24:17 for :22, 3.21 ms with 24:19:22; the 64-wide shape then moved from a per-wave split to
+// the shared one: 3.16 ms with :17; the narrow shapes run below their MFMA count): the cost model of the slab split.
+static const int kShapeCost[6] = {24, 19, 17, 8, 8, 8};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     // A workgroup takes a whole CU (512 registers per lane), so the grid is sized

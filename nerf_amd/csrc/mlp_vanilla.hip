@@ -488,8 +488,8 @@ extern "C" int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, in
     int n = 0;
     // The narrow parts (4 MFMAs per k-step) wait on memory rather than on the MFMA pipe
     // and run longer than their MFMA count says: dispatch them first, the wide ones after.
-    parts.part[n++] = wgrad_part_desc(DY(0), 256, XE, 64, grads[0], 63, 0, 63, grads[1], 2);
-    parts.part[n++] = wgrad_part_desc(DY(4), 256, XE, 64, grads[8], 319, xe_col, 63, nullptr, 2);
+    parts.part[n++] = with_max(wgrad_part_desc(DY(0), 256, XE, 64, grads[0], 63, 0, 63, grads[1], 2), 0, vw::SLOT_XE);
+    parts.part[n++] = with_max(wgrad_part_desc(DY(4), 256, XE, 64, grads[8], 319, xe_col, 63, nullptr, 2), 4, vw::SLOT_XE);
     parts.part[n++] = with_max(wgrad_part_desc(DYR, 128, FEAT, 256, grads[20], 283, 0, 256, grads[21], 1, DE, 32, 256, 27), 9,
                                vw::SLOT_FEAT, vw::SLOT_DE);
     for (int l = 1; l < 8; ++l)
