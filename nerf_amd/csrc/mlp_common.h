@@ -68,13 +68,12 @@ __device__ __forceinline__ void dense(const float* __restrict__ wp, const f32x16
 // workgroup copies the weights into LDS once, each wave a quarter, and every wave
 // reads its operands from there.
 //
-// The packed weights of consecutive dense() calls form one stream of chunks of 16
-// k-steps (at most 32 KiB).  Three chunk buffers rotate.  In the middle of chunk g
-// every wave waits for its own copies of chunk g+1, the workgroup meets at a
-// barrier (so chunk g+1 is complete, and nobody reads chunk g-1 any more), and the
-// copies of chunk g+2 go out into the buffer chunk g-1 occupied.  The barrier sits
-// between two MFMA groups with the next operands already requested, so the pipe
-// only sees the skew between the waves.  All four waves must make the same calls.
+// The packed weights of consecutive dense_h3() calls form one stream of 16-KiB chunks through a ring of
+// chunk buffers.  In the middle of chunk g every wave waits for its own copies of chunk g+1, the workgroup
+// meets at a barrier (so chunk g+1 is complete, and nobody reads chunk g-1 any more), and the copies of
+// chunk g+RING-1 go out into the buffer chunk g-1 occupied.  The barrier sits between two MFMA groups with the
+// next operands already requested, so the pipe only sees the skew between the waves.  All four waves must make
+// the same calls.  (Details with dense_h3 below.)
 //
 // Every LDS access here is asm: the compiler makes each LDS access it knows of
 // wait for all direct-to-LDS copies in flight, and orders loads by its own model.
@@ -106,7 +105,7 @@ __device__ __forceinline__ int wrap3(int x) { return x >= 3 ? x - 3 : x; }
 
 struct WeightStream {
     float* lds;   // the chunk buffers shared by the workgroup
-    int g3;       // buffer of the chunk the next dense layer starts with
+    int g3;       // ring buffer of the chunk the next dense layer starts with
     int wave, lane;
     const float* next = nullptr;   // the next chunk to copy, and where the packed layers end
     const float* end = nullptr;
