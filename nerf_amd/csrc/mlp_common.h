@@ -748,6 +748,9 @@ struct WgradPart {
     const unsigned* amaxY;   // the largest |entry| of dY, X, X2 as float bit patterns in device memory (the split-f16
     const unsigned* amaxX;   // shapes scale their operands by them); null: the matrix is used as it is
     const unsigned* amaxX2;
+    const float* sk_d;       // optional rider on a split-f16 part: a per-point scalar d[P32] whose product with X is
+    float* sk_dW;            // accumulated alongside, sk_dW[k] += sum_p d[p] X[p][k], sk_db[0] += sum_p d[p] (the gradient
+    float* sk_db;            // of a one-output head that reads the same X, in plain fp32 on the lanes that load X)
     int shape;         // index into the (NTW, KT, KT2) instantiation list
     int slabs;         // point slabs this part is split into
     int first_block;   // prefix sum of slabs

@@ -342,7 +342,7 @@ __device__ __forceinline__ PointScale part_scale(const unsigned* amax) {
     return amax ? scale_for_max(*amax) : PointScale{1.0f, 1.0f};
 }
 
-template <int NTW, int KT, int KT2, int GROUP>
+template <int NTW, int KT, int KT2, int GROUP, bool SK = false>
 __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
                                               float* lds) {
     constexpr int NT = 4 * NTW, KTT = KT + KT2, TILES = NT + KTT, J = KTT / GROUP, NM = 3 * NTW * GROUP;
@@ -386,6 +386,18 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
     const unsigned rd_a_off = NTW * wave * PK_TILE_BYTES + lane * 16, rd_b_off = lane * 16;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of this lane's dY columns (the bias gradient)
     float4 R[2][8];
+    // the rider (see WgradPart::sk_d): this lane's eight points of the per-point scalar, and its sums
+    constexpr bool sk = SK;
+    const float* sk_src = sk ? pt.sk_d + 8 * ps : nullptr;
+    float4 D[2][2];
+    float sk_acc[4] = {0.f, 0.f, 0.f, 0.f}, sk_sum = 0.0f, dl0 = 0.0f, dl1 = 0.0f;
+    auto load_d = [&](auto cu, long long p) {
+        if constexpr (sk) {
+            const long long pc = p < p_end ? p : p_end - 16;
+            D[decltype(cu)::value][0] = *reinterpret_cast<const float4*>(sk_src + pc);
+            D[decltype(cu)::value][1] = *reinterpret_cast<const float4*>(sk_src + pc + 4);
+        }
+    };
     // Request row q of a k-step.  Never skipped, so that the compiler's count of requests in flight stays exact:
     // past the end the last k-step is read again and ignored.
     auto load_row = [&](auto cu, auto cq, long long p) {
@@ -393,7 +405,10 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
         const f32x4 ld4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (pc + decltype(cq)::value) * ld));
         R[decltype(cu)::value][decltype(cq)::value] = make_float4(ld4[0], ld4[1], ld4[2], ld4[3]);
     };
-    auto load_raw = [&](auto cu, long long p) { static_for<0, 8>([&](auto cq) { load_row(cu, cq, p); }); };
+    auto load_raw = [&](auto cu, long long p) {
+        static_for<0, 8>([&](auto cq) { load_row(cu, cq, p); });
+        load_d(cu, p);
+    };
     // Splitting a k-step is 40 chunks of at most six mutually independent instructions, one chunk per MFMA:
     // a dependent instruction issued right behind its producer waits ~9 clocks and holds up the MFMA queued
     // behind it, whereas up to six independent ones issue under an MFMA for free.  Chunk 8e + 4g + level
@@ -423,11 +438,22 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
                     t_x1[j] = sub_f16<1>(t_x1[j], PH[c][e]);
                 } else {
                     PL[c][e] = cvt_pk_f16(t_x0[j], t_x1[j]);
+                    if constexpr (sk) sk_acc[c] = fmaf(x0, dl0, fmaf(x1, dl1, sk_acc[c]));
+                }
+            }
+            if constexpr (sk && g == 0) {   // the rider's two points of this row pair, zero past the end
+                const float4 dq = D[u][e / 2];
+                if constexpr (lv == 1) {
+                    dl0 = live * (e % 2 == 0 ? dq.x : dq.z);
+                    dl1 = live * (e % 2 == 0 ? dq.y : dq.w);
+                } else if constexpr (lv == 2) {
+                    sk_sum += dl0 + dl1;
                 }
             }
             if constexpr (k % 8 == 7) {
                 load_row(cu, std::integral_constant<int, 2 * e>{}, p_next);
                 load_row(cu, std::integral_constant<int, 2 * e + 1>{}, p_next);
+                if constexpr (e == 3) load_d(cu, p_next);
             }
         } else {   // one store per chunk: the four waves are in step and their stores would arrive together
             constexpr int c = (k - 32) / 2, part = (k - 32) % 2;
@@ -526,6 +552,12 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
         for (int c = 0; c < 4; ++c)
             if (32 * T + 4 * pj + c < pt.n_valid) atomicAdd(pt.dbias + 32 * T + 4 * pj + c, bsum[c]);
     }
+    if (sk && pt.sk_d && T >= NT && T < NT + KT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (32 * (T - NT) + 4 * pj + c < pt.k_valid) atomicAdd(pt.sk_dW + 32 * (T - NT) + 4 * pj + c, sk_acc[c]);
+        if (pt.sk_db && T == NT && pj == 0) atomicAdd(pt.sk_db, sk_sum);
+    }
 }
 
 // shape ids (NTW,KT,KT2,NW): 0 = <2,8,0,4>  1 = <1,8,1,4>  2 = <2,2,0,4>   (a 320-register <2,8,2> tile set does
@@ -543,7 +575,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     if (t0 >= t1) return;   // uniform for the whole workgroup
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     switch (pt.shape) {
-        case 0: wgrad_part_pk<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        case 0:
+            if (pt.sk_d) wgrad_part_pk<2, 8, 0, 2, true>(pt, t0 * 32, t1 * 32, wave, lane, lds);
+            else wgrad_part_pk<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds);
+            break;
         case 1: wgrad_part_pk<1, 8, 1, 3>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 2: wgrad_part_pk<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 3: wgrad_part<1, 1, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;

@@ -56,7 +56,8 @@ constexpr int DFEAT = 8 * 256;
 constexpr int DYR = DFEAT + 256;   // [P32][128]
 constexpr int DOUT4 = DYR + 128;   // [P32][4] = (d sigma_pre, d rgb_pre[3])
 constexpr int AMAX2 = DOUT4 + 4;   // the same for the gradient matrices: slots d y0..d y7, d feat, d hr
-constexpr int PER_POINT2 = AMAX2 + 4;
+constexpr int DPS = AMAX2 + 4;     // [P32] d sigma_pre once more, contiguous (the weight-gradient kernel reads 8 points at a time)
+constexpr int PER_POINT2 = DPS + 1;
 }  // namespace vw
 
 struct TileIdx {
@@ -260,7 +261,10 @@ __global__ __launch_bounds__(256) void vanilla_bwd_data_kernel(const float* __re
         dpre[c] = ix.valid ? d_rgb[3 * ix.lp + c] * o * (1.0f - o) : 0.0f;   // sigmoid'
     }
     if (ix.valid) dps = d_sigma[ix.lp] * (1.0f - expf(-sigma[ix.lp]));          // softplus' = 1 - exp(-softplus)
-    if (h == 0) *reinterpret_cast<float4*>(ws2 + ix.P32 * vw::DOUT4 + ix.gp * 4) = make_float4(dps, dpre[0], dpre[1], dpre[2]);
+    if (h == 0) {
+        *reinterpret_cast<float4*>(ws2 + ix.P32 * vw::DOUT4 + ix.gp * 4) = make_float4(dps, dpre[0], dpre[1], dpre[2]);
+        ws2[ix.P32 * vw::DPS + ix.gp] = dps;
+    }
     ws_ready();
 
     // The wave's largest |entry| of each gradient matrix (see launch_amax_reduce).
@@ -495,12 +499,16 @@ extern "C" int nerf_mlp_vanilla_bwd(const float* d_rgb, const float* d_sigma, in
     for (int l = 1; l < 8; ++l)
         parts.part[n++] = with_max(wgrad_part_desc(DY(l), 256, H(l - 1), 256, grads[2 * l], l == 4 ? 319 : 256,
                                                    l == 4 ? h_col : 0, 256, grads[2 * l + 1], 0), l, vw::SLOT_H + l - 1);
-    parts.part[n++] = with_max(wgrad_part_desc(DFEAT, 256, H(7), 256, grads[18], 256, 0, 256, grads[19], 0), 8, vw::SLOT_H + 7);
+    {   // the feature layer's part also forms the density head's gradient: the same h7 rows times d sigma_pre
+        WgradPart pf = with_max(wgrad_part_desc(DFEAT, 256, H(7), 256, grads[18], 256, 0, 256, grads[19], 0), 8, vw::SLOT_H + 7);
+        pf.sk_d = ws2 + P32 * vw::DPS;
+        pf.sk_dW = grads[16];
+        pf.sk_db = grads[17];
+        parts.part[n++] = pf;
+    }
     parts.n = n;
     if (int rc = launch_wgrad(parts, P32, st)) return rc;
 
-    SkinnyPart sg{DOUT4, H(7), grads[16], grads[17], 4, 256, 0, 1, 256};
-    if (int rc = launch_skinny(sg, P32, st)) return rc;
     SkinnyPart rg{DOUT4, HR, grads[22], grads[23], 4, 128, 1, 3, 128};
     return launch_skinny(rg, P32, st);
 }
