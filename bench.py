@@ -305,6 +305,11 @@ def kernel_roofline(model, rays, dev):
                     "per point x points / HIP-event time, peak 8 TB/s) or the matrix cores (achieved = algorithmic fp32-equivalent "
                     "FLOP/s, peak = 2500 TFLOP/s dense f16 / 3 f16 MFMAs per fp32 product; the exact-f32 MFMA peak is 157.3)",
             "mfma_frac": tflops / peak_mfma, "hbm_frac": gbs / PEAK_HBM_GBS, "executed_f16_tflops": tflops * MFMA_PER_PRODUCT,
+            "fp32_equivalent_tflops": tflops,
+            "frac_of_six_mfma_roofline": tflops / (PEAK_F16_MATRIX_TFLOPS / 6),
+            "note_six": "until the middle of round 2 a product was six bf16 MFMAs (roofline 416.7 fp32-equivalent TFLOP/s, kernels at "
+                        "0.49-0.54 of it); halving the MFMAs per product halves the executed-MFMA fraction of the same time, so "
+                        "the fp32-equivalent rate against that earlier roofline is given for comparison",
             "all_kernels": per_kernel,
             "all_kernels_ms": {k: v[0] * 1e3 for k, v in kernels.items()}}
 
