@@ -101,7 +101,12 @@ class GradBuckets:
     def _send(self, bi: int) -> None:
         self._sent[bi] = True
         if self.world > 1:
-            self._work[bi] = dist.all_reduce(self.flats[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            flat = self.flats[bi]
+            if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+                # rehearsal of the multi-GPU path with ranks sharing a GPU: gloo's staging copy of a CUDA tensor
+                # was seen to wait forever when kernels are still pending on the tensor's stream
+                torch.cuda.current_stream(flat.device).synchronize()
+            self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _delivered(self, bi: int) -> None:
         if not self._armed or not self.overlap:
