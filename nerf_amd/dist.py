@@ -47,10 +47,13 @@ class GradBuckets:
     Scale the loss by ``1 / world`` (``grad_scale``) to get the average.
     """
 
-    def __init__(self, buckets: Sequence, group=None, overlap: bool = True):
+    def __init__(self, buckets: Sequence, group=None, overlap: bool = True, always_reduce: bool = False):
         """``overlap=False`` issues every bucket's all-reduce from ``finish()`` (the calling thread) instead of
-        from the gradient hooks: no overlap with backward, the plainest use of the process group."""
+        from the gradient hooks: no overlap with backward, the plainest use of the process group.
+        ``always_reduce=True`` issues the all-reduces in a one-rank group too (a sum over one rank): the whole
+        exchange path, collectives included, can then be exercised on a single GPU."""
         self.overlap = overlap
+        self.always_reduce = always_reduce
         if buckets and isinstance(buckets[0], torch.nn.Parameter):
             buckets = [list(buckets)]
         self.group = group
@@ -100,7 +103,7 @@ class GradBuckets:
 
     def _send(self, bi: int) -> None:
         self._sent[bi] = True
-        if self.world > 1:
+        if self.world > 1 or (self.always_reduce and dist.is_available() and dist.is_initialized()):
             flat = self.flats[bi]
             if flat.is_cuda and dist.get_backend(self.group) == "gloo":
                 # rehearsal of the multi-GPU path with ranks sharing a GPU: gloo's staging copy of a CUDA tensor
