@@ -130,6 +130,16 @@ def main():
         t = timeit(lambda: m(xs, dirs, dirs_div=N), iters=5)
     report("ngp_fwd fused (hash + MLPs, inference)", P * (16 * 8 * 8 + 12 + 16), t, "gather-bound; 13.8 kFLOP/point of MFMA on top")
 
+    # the vanilla MLP's inference forward (what render_image runs): matrix-core work, reported as FLOP/s
+    from nerf_amd.models.NeRF import NeRF
+    vm = NeRF().to(dev)
+    with torch.no_grad():
+        t = timeit(lambda: ops.vanilla_mlp(xs, dirs, vm._params(), False, dirs_div=N), iters=5)
+    flop = 2 * 593408 * P
+    print(json.dumps({"kernel": "vanilla_fwd (8x256 MLP, inference, %d points)" % P, "ms": t * 1e3,
+                      "fp32_equivalent_TFLOP/s": flop / t / 1e12, "frac_of_f16_peak_over_3": flop / t / 1e12 / (2500.0 / 3),
+                      "Mpoints/s": P / t / 1e6, "note": "no activations saved; 3 f16 MFMAs per fp32 product"}), flush=True)
+
 
 if __name__ == "__main__":
     main()
