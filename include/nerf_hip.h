@@ -158,6 +158,12 @@ int nerf_occupancy_mask(const float* pts, const float* values, int64_t P, const 
  *   W0,b0, ... ,W7,b7, Wsigma,bsigma, Wfeat,bfeat, Wrgb0,brgb0, Wrgb2,brgb2
  * with the nn.Linear shapes (out,in): (256,63) (256,256)x3 (256,319)
  * (256,256)x3 (1,256) (256,256) (128,283) (3,128).
+ *
+ * Numerics: fp32 in and out with fp32 accuracy (the forward pass agrees with a float64
+ * evaluation to 1e-7).  Products run on the f16 matrix pipe as three MFMAs over two-piece
+ * splits of the fp32 operands; the kernels keep the pieces in range themselves with exact
+ * power-of-two factors per point and per saved matrix, so no loss scaling or clamping is
+ * asked of the caller, whatever the magnitude of activations and gradients.
  */
 #define NERF_VANILLA_NPARAM 24
 
