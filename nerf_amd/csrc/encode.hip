@@ -122,15 +122,21 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_pinned_kernel(const float* _
 // the feature, bit 1 the x offset of the corner, so the (up to) four adds that fall into one
 // 16-byte stretch of the table (both features of rows r and r+1: the hash is linear in x)
 // travel in one instruction and, unless the row wraps, in one line.
+// The gradient of feature f of level l of point p: d_out is row-major [P][2 * levels] (level_stride 0) or
+// level-major [levels][level_stride][2].
+__device__ __forceinline__ int64_t denc_index(int64_t p, int l, int levels, int64_t level_stride) {
+    return level_stride ? 2 * ((int64_t)l * level_stride + p) : p * (2 * levels) + 2 * l;
+}
+
 __global__ void hashgrid_bwd_kernel(const float* __restrict__ x, int64_t P, const float* __restrict__ d_out,
-                                    HashGradLevels lv, int levels) {
+                                    HashGradLevels lv, int levels, int64_t level_stride) {
     const int j = blockIdx.y, l = lv.id[j];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t >> 2;
     if (p >= P) return;
     const int f = (int)t & 1, cx = ((int)t >> 1) & 1;
     const Cell c = locate(x, p, lv.res[j]);
-    const float g = d_out[p * (2 * levels) + 2 * l + f];
+    const float g = d_out[denc_index(p, l, levels, level_stride) + f];
     float* __restrict__ tab = lv.table[j] + f;
     const unsigned size = lv.size[j];
     const unsigned px = cx ? c.hi[0] : c.lo[0];
@@ -151,7 +157,8 @@ constexpr int HG_LDS_THREADS = 1024;
 constexpr unsigned HG_LDS_MAX_ROWS = 8192;   // 128 KiB of LDS
 __global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const float* __restrict__ x, int64_t P,
                                                                           const float* __restrict__ d_out, float* tab,
-                                                                          int res, unsigned size, int l, int levels) {
+                                                                          int res, unsigned size, int l, int levels,
+                                                                          int64_t level_stride) {
     extern __shared__ double s_tab[];   // [size][2]
     const int tid = threadIdx.x;
     for (unsigned i = tid; i < 2 * size; i += HG_LDS_THREADS) s_tab[i] = 0.0;
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const 
         const int64_t p = t >> 2;
         const int f = (int)t & 1, cx = ((int)t >> 1) & 1;
         const Cell c = locate(x, p, res);
-        const float g = d_out[p * (2 * levels) + 2 * l + f];
+        const float g = d_out[denc_index(p, l, levels, level_stride) + f];
         const unsigned px = cx ? c.hi[0] : c.lo[0];
         const float wx = cx ? c.w[0] : 1.0f - c.w[0];
 #pragma unroll
@@ -185,60 +192,97 @@ __global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const 
 // many times over (4.2 M points x 8 corners into 524,288 rows: 64 updates per row), but scattered float
 // atomics are executed one line at a time at the memory side (~20 G transactions/s) whoever shares the
 // row.  So the updates are first sorted by table segment and then summed in LDS:
-//   pass 1 (bin): a workgroup of 512 points turns every (point, level) into 4 records -- one per (y, z)
-//     corner pair: row of the low-x corner within its 16,384-row segment + the four values for rows r and
-//     r+1 (the hash is linear in x) -- counting-sorts them by segment in LDS and appends each run to that
-//     segment's queue in the workspace (one reservation atomic per segment, coalesced stores);
+//   pass 1 (bin): a workgroup of 512 points turns every (point, level) into 4 records of 16 bytes -- one per
+//     (y, z) corner pair: the row r of the low-x corner within its 8,192-row segment, the two updates of row r
+//     (a, b) and the ratio rho = wx / (1 - wx) of the high-x to the low-x weight, so that row r + 1 (the hash is
+//     linear in x) receives (rho a, rho b) -- counting-sorts them by segment in LDS and appends each run to that
+//     segment's queue in the workspace.  A run is padded with empty records to whole 128-byte lines and the
+//     queues start on line boundaries: every line of a queue is written once, whole, by one instruction (runs that
+//     start anywhere cost a read-modify-write of their first and last lines at the memory side).  A segment has
+//     several queues, a workgroup appending to queue (its index % nsub): the space of a run is reserved by a
+//     returning atomic on the queue's counter, atomics on one cache line are executed one after the other at the
+//     memory side, and with one queue per segment every workgroup of the grid queues up at the same two lines.
 //   pass 2 (reduce): a workgroup zeroes a 128 KiB LDS image of one 8,192-row segment, adds a slice of its
 //     queue with LDS atomics and adds the image to the table contiguously.
 // The LDS image is DOUBLE: measured on this chip, ds_add_f32 is executed one lane at a time (192 cycles per
 // wave instruction whatever the addresses; ds_add_rtn_f32 the same) while ds_add_f64 takes 8-26 and
 // ds_add_u32 5-8.  Float sums in LDS are therefore kept as doubles, which also makes them exact enough
-// that the order of the additions stops mattering.
-// Records whose queue is full (the capacity is 1.25 x the even share) and high-x corners that do not sit
-// in the row after their partner (x wrap, segment boundary) go to the table directly.
+// that the order of the additions stops mattering.  (rho a is formed in double from the two floats: it differs
+// from the float product of the high-x weight and the gradient by a few units in the last place of a float.)
+// Records whose queue is full (the capacity is 1.25 x the even share plus the padding) and high-x corners that
+// do not sit in the row after their partner (x wrap, segment boundary) go to the table directly.
 // ---------------------------------------------------------------------------
 constexpr int BIN_SEG_ROWS = 8192;    // 128 KiB of double2
 constexpr int BIN_PTS = 512;
 constexpr int BIN_REC = 4 * BIN_PTS;
 constexpr int BIN_MAX_SEGS = 64;
+constexpr int BIN_RUN = 8;            // records per 128-byte line
+constexpr int BIN_SLOTS = BIN_REC + BIN_MAX_SEGS * (BIN_RUN - 1);   // a workgroup's records of a level, every run padded
+constexpr int BIN_MIN_SUB = 8;        // queues per segment at least; a reduce workgroup takes at most this many
 constexpr unsigned BIN_NO_DEST = 0xffffffffu;
 constexpr long long BIN_SLICE_RECORDS = 131072;
 struct BinLevels {
     float* table[HG_MAX_LEVELS];
-    long long q_off[HG_MAX_LEVELS];     // dword offset of the level's queues: 5 component arrays of nseg * cap dwords
+    long long q_off[HG_MAX_LEVELS];     // record offset of the level's queues
     int res[HG_MAX_LEVELS];
     unsigned size[HG_MAX_LEVELS];
     int id[HG_MAX_LEVELS];              // position of the level in the encoding
     int nseg[HG_MAX_LEVELS];
-    int seg_first[HG_MAX_LEVELS + 1];   // prefix sum of nseg: index of the level's first counter
-    int slices[HG_MAX_LEVELS];
+    int nsub[HG_MAX_LEVELS];            // queues per segment: a bin workgroup appends to queue (its index % nsub)
+    int cnt_first[HG_MAX_LEVELS + 1];   // prefix sum of nseg * nsub: the level's first counter, laid out [sub][segment]
+    int slices[HG_MAX_LEVELS];          // reduce workgroups per segment; workgroup r takes queues r, r + slices, ...
     int wg_first[HG_MAX_LEVELS + 1];    // prefix sum of nseg * slices: the level's first reduce workgroup
-    unsigned cap[HG_MAX_LEVELS];        // records per segment queue
+    unsigned cap[HG_MAX_LEVELS];        // records per queue, a multiple of BIN_RUN; queues laid out [segment][sub][cap]
     int n;
 };
 
-__global__ __launch_bounds__(BIN_PTS) void hashgrid_bin_kernel(const float* __restrict__ x, int64_t P,
-                                                               const float* __restrict__ d_out, int levels, BinLevels lv,
-                                                               unsigned* __restrict__ counters, float* __restrict__ queues) {
+// locate() of hashgrid.h on coordinates already in registers
+__device__ __forceinline__ Cell locate3(const float (&xyz)[3], int res) {
+    Cell c;
+    const float inv_res = 1.0f / (float)res;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float pos = xyz[k] * (float)res;
+        const float fl = floorf(pos);
+        c.w[k] = pos - fl;
+        if (fabsf(fl) < 16777216.0f) {
+            c.lo[k] = wrap_small(fl, res, inv_res);
+            c.hi[k] = c.lo[k] + 1 == (unsigned)res ? 0u : c.lo[k] + 1;
+        } else {
+            const long long p0 = (long long)fl;
+            c.lo[k] = wrap(p0, res);
+            c.hi[k] = wrap(p0 + 1, res);
+        }
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* __restrict__ x, int64_t P,
+                                                               const float* __restrict__ d_out, int levels,
+                                                               int64_t level_stride, BinLevels lv,
+                                                               unsigned* __restrict__ counters, float4* __restrict__ queues) {
     __shared__ unsigned s_hist[BIN_MAX_SEGS], s_start[BIN_MAX_SEGS + 1], s_gbase[BIN_MAX_SEGS];
-    __shared__ unsigned s_dest[BIN_REC];
-    __shared__ float s_rec[5][BIN_REC];
+    __shared__ unsigned s_dest[BIN_SLOTS];
+    __shared__ float4 s_rec[BIN_SLOTS];
     const int tid = threadIdx.x;
     const int64_t p = (int64_t)blockIdx.x * BIN_PTS + tid;
     const bool valid = p < P;
     const int64_t pl = valid ? p : P - 1;
+    const float xyz[3] = {x[3 * pl], x[3 * pl + 1], x[3 * pl + 2]};
+    float2 g_next = *reinterpret_cast<const float2*>(d_out + denc_index(pl, lv.id[0], levels, level_stride));
 #pragma unroll 1
     for (int j = 0; j < lv.n; ++j) {
         const unsigned size = lv.size[j], cap = lv.cap[j];
-        const int nseg = lv.nseg[j];
+        const int nseg = lv.nseg[j], nsub = lv.nsub[j], sub = blockIdx.x % nsub;
+        const float2 g = g_next;   // requested an iteration ago
+        if (j + 1 < lv.n) g_next = *reinterpret_cast<const float2*>(d_out + denc_index(pl, lv.id[j + 1], levels, level_stride));
         float* __restrict__ tab = lv.table[j];
         if (tid < BIN_MAX_SEGS) s_hist[tid] = 0u;
         __syncthreads();
-        const Cell c = locate(x, pl, lv.res[j]);
-        const float2 g = *reinterpret_cast<const float2*>(d_out + pl * (2 * levels) + 2 * lv.id[j]);
+        const Cell c = locate3(xyz, lv.res[j]);
+        const float rho = c.w[0] / (1.0f - c.w[0]);   // w is a fractional part: 1 - w > 0
         unsigned seg[4], pos[4], loc[4];
-        float v[4][4];
+        float va[4], vb[4], vr[4];
 #pragma unroll
         for (int yz = 0; yz < 4; ++yz) {
             const unsigned cy = (yz & 2) ? c.hi[1] : c.lo[1], cz = (yz & 1) ? c.hi[2] : c.lo[2];
@@ -248,10 +292,9 @@ __global__ __launch_bounds__(BIN_PTS) void hashgrid_bin_kernel(const float* __re
             seg[yz] = r_lo / BIN_SEG_ROWS;
             loc[yz] = r_lo % BIN_SEG_ROWS;
             const bool pair = r_hi == r_lo + 1 && loc[yz] != BIN_SEG_ROWS - 1;
-            v[yz][0] = w_lo * g.x;
-            v[yz][1] = w_lo * g.y;
-            v[yz][2] = pair ? w_hi * g.x : 0.0f;
-            v[yz][3] = pair ? w_hi * g.y : 0.0f;
+            va[yz] = w_lo * g.x;
+            vb[yz] = w_lo * g.y;
+            vr[yz] = pair ? rho : 0.0f;
             if (valid && !pair) {
                 atomicAdd(tab + 2 * (size_t)r_hi, w_hi * g.x);
                 atomicAdd(tab + 2 * (size_t)r_hi + 1, w_hi * g.y);
@@ -260,16 +303,20 @@ __global__ __launch_bounds__(BIN_PTS) void hashgrid_bin_kernel(const float* __re
         }
         __syncthreads();
         if (tid < nseg) {
-            const unsigned cnt = s_hist[tid];
-            s_gbase[tid] = cnt ? atomicAdd(&counters[lv.seg_first[j] + tid], cnt) : 0u;
+            const unsigned cnt = s_hist[tid], padded = (cnt + BIN_RUN - 1) & ~(unsigned)(BIN_RUN - 1);
+            s_gbase[tid] = cnt ? atomicAdd(&counters[lv.cnt_first[j] + sub * nseg + tid], padded) : 0u;
         }
-        if (tid == 2 * BIN_MAX_SEGS) {   // another wave than those reserving queue space
-            unsigned run = 0u;
-            for (int k = 0; k < nseg; ++k) {
-                s_start[k] = run;
-                run += s_hist[k];
+        if (tid >= 2 * BIN_MAX_SEGS && tid < 3 * BIN_MAX_SEGS) {   // another wave than the one reserving queue space:
+            const int k = tid - 2 * BIN_MAX_SEGS;                   // prefix sums of the padded run lengths, one lane per segment
+            const unsigned len = k < nseg ? (s_hist[k] + BIN_RUN - 1) & ~(unsigned)(BIN_RUN - 1) : 0u;
+            unsigned incl = len;
+#pragma unroll
+            for (int d = 1; d < 64; d *= 2) {
+                const unsigned up = __shfl_up(incl, d, 64);
+                if (k >= d) incl += up;
             }
-            s_start[BIN_MAX_SEGS] = run;
+            s_start[k] = incl - len;
+            if (k == BIN_MAX_SEGS - 1) s_start[BIN_MAX_SEGS] = incl;
         }
         __syncthreads();
         if (valid) {
@@ -277,74 +324,103 @@ __global__ __launch_bounds__(BIN_PTS) void hashgrid_bin_kernel(const float* __re
             for (int yz = 0; yz < 4; ++yz) {
                 const unsigned i = s_start[seg[yz]] + pos[yz], gq = s_gbase[seg[yz]] + pos[yz];
                 if (gq < cap) {
-                    s_dest[i] = seg[yz] * cap + gq;
-                    s_rec[0][i] = __uint_as_float(loc[yz]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) s_rec[1 + k][i] = v[yz][k];
+                    s_dest[i] = (seg[yz] * nsub + sub) * cap + gq;
+                    s_rec[i] = make_float4(__uint_as_float(loc[yz]), va[yz], vb[yz], vr[yz]);
                 } else {   // the segment's queue is full
                     s_dest[i] = BIN_NO_DEST;
                     float* row = tab + 2 * ((size_t)seg[yz] * BIN_SEG_ROWS + loc[yz]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (v[yz][k] != 0.0f) atomicAdd(row + k, v[yz][k]);
+                    if (va[yz] != 0.0f) atomicAdd(row, va[yz]);
+                    if (vb[yz] != 0.0f) atomicAdd(row + 1, vb[yz]);
+                    if (vr[yz] != 0.0f) {   // a pair: the high-x corner's update, formed as on the direct path
+                        const float wy = (yz & 2) ? c.w[1] : 1.0f - c.w[1], wz = (yz & 1) ? c.w[2] : 1.0f - c.w[2];
+                        const float w_hi = (c.w[0] * wy) * wz;
+                        atomicAdd(row + 2, w_hi * g.x);
+                        atomicAdd(row + 3, w_hi * g.y);
+                    }
                 }
+            }
+        }
+        if (tid < nseg) {   // empty records up to the end of the run's last line (row BIN_SEG_ROWS is the image's spare row)
+            const unsigned cnt = s_hist[tid], padded = (cnt + BIN_RUN - 1) & ~(unsigned)(BIN_RUN - 1);
+            for (unsigned k = cnt; k < padded; ++k) {
+                const unsigned gq = s_gbase[tid] + k;
+                s_dest[s_start[tid] + k] = gq < cap ? (tid * nsub + sub) * cap + gq : BIN_NO_DEST;
+                s_rec[s_start[tid] + k] = make_float4(__uint_as_float((unsigned)BIN_SEG_ROWS), 0.0f, 0.0f, 0.0f);
             }
         }
         __syncthreads();
         const unsigned n_rec = s_start[BIN_MAX_SEGS];
-        float* __restrict__ q = queues + lv.q_off[j];
-        const size_t comp = (size_t)nseg * cap;
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-            for (unsigned i = tid; i < n_rec; i += BIN_PTS) {
-                const unsigned d = s_dest[i];
-                if (d != BIN_NO_DEST) q[k * comp + d] = s_rec[k][i];
-            }
+        float4* __restrict__ q = queues + lv.q_off[j];
+        for (unsigned i = tid; i < n_rec; i += BIN_PTS) {
+            const unsigned d = s_dest[i];
+            if (d != BIN_NO_DEST) q[d] = s_rec[i];
+        }
         __syncthreads();
     }
 }
 
 constexpr int RED_THREADS = 1024;
 __global__ __launch_bounds__(RED_THREADS) void hashgrid_reduce_kernel(BinLevels lv, const unsigned* __restrict__ counters,
-                                                                      const float* __restrict__ queues) {
+                                                                      const float4* __restrict__ queues) {
     extern __shared__ double s_tab[];   // [BIN_SEG_ROWS + 2][2]: a record's second row may be the one past the segment
+    typedef float f32x4n __attribute__((ext_vector_type(4)));
     int j = 0;
 #pragma unroll 1
     while (j + 1 < lv.n && (int)blockIdx.x >= lv.wg_first[j + 1]) ++j;
-    const int w = blockIdx.x - lv.wg_first[j], slices = lv.slices[j];
-    const int sg = w / slices, slice = w - sg * slices;
+    const int w = blockIdx.x - lv.wg_first[j], slices = lv.slices[j], nseg = lv.nseg[j], nsub = lv.nsub[j];
+    const int sg = w / slices, first_sub = w - sg * slices;
     const unsigned cap = lv.cap[j];
-    const unsigned have = counters[lv.seg_first[j] + sg];
-    const unsigned long long cnt = have < cap ? have : cap;
-    const unsigned lo = (unsigned)(cnt * slice / slices), hi = (unsigned)(cnt * (slice + 1) / slices);
-    if (lo >= hi) return;   // the whole workgroup
+    // This workgroup's queues (at most BIN_MIN_SUB of them) as one run of records: queue m starts at pre[m].
+    const unsigned* __restrict__ cnt_of = counters + lv.cnt_first[j] + sg;   // [sub * nseg]
+    unsigned pre[BIN_MIN_SUB + 1];
+    pre[0] = 0u;
+#pragma unroll
+    for (int m = 0; m < BIN_MIN_SUB; ++m) {
+        const int sub = first_sub + m * slices;
+        unsigned have = sub < nsub ? cnt_of[sub * nseg] : 0u;
+        have = have < cap ? have : cap;
+        pre[m + 1] = pre[m] + have;
+    }
+    const unsigned total = pre[BIN_MIN_SUB];
+    if (total == 0) return;   // the whole workgroup
     const unsigned row0 = (unsigned)sg * BIN_SEG_ROWS;
     const unsigned rows = min((unsigned)BIN_SEG_ROWS, lv.size[j] - row0);
     const int tid = threadIdx.x;
     for (unsigned i = tid; i < 2 * rows + 2; i += RED_THREADS) s_tab[i] = 0.0;
     __syncthreads();
-    const size_t comp = (size_t)lv.nseg[j] * cap;
-    const float* __restrict__ q = queues + lv.q_off[j] + (size_t)sg * cap;
-    // Eight records per thread and round, all forty loads first: one workgroup per CU (the LDS image) has only its
-    // own loads to cover the memory latency with.
+    const f32x4n* __restrict__ q = reinterpret_cast<const f32x4n*>(queues + lv.q_off[j] + ((size_t)sg * nsub + first_sub) * cap);
+    const size_t q_stride = (size_t)slices * cap;   // from one of this workgroup's queues to the next
+    // Eight records per thread and round, all loads first: one workgroup per CU (the LDS image) has only its own
+    // loads to cover the memory latency with.  (What bounds this kernel is the LDS double atomics, about 1.25
+    // lanes per clock at random rows: loading a round ahead of the atomics changed nothing.)  Padding records and
+    // lanes past the end skip theirs.
     constexpr int UNR = 8;
-    for (unsigned i0 = lo + tid; i0 < hi; i0 += UNR * RED_THREADS) {
-        unsigned loc[UNR];
-        float v[UNR][4];
+    for (unsigned k0 = tid; k0 < total; k0 += UNR * RED_THREADS) {
+        f32x4n r[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const unsigned i = i0 + u * RED_THREADS;
-            const bool ok = i < hi;
-            const unsigned ic = ok ? i : i0;
-            loc[u] = ok ? __float_as_uint(__builtin_nontemporal_load(q + ic)) : BIN_SEG_ROWS;   // the spare row pair
+            const unsigned k = k0 + u * RED_THREADS, kc = k < total ? k : k0;
+            unsigned m = 0, start = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[u][k] = __builtin_nontemporal_load(q + (k + 1) * comp + ic);
+            for (int t = 1; t < BIN_MIN_SUB; ++t)
+                if (kc >= pre[t]) {
+                    m = t;
+                    start = pre[t];
+                }
+            r[u] = __builtin_nontemporal_load(q + m * q_stride + (kc - start));
+            if (k >= total) r[u][0] = __uint_as_float((unsigned)BIN_SEG_ROWS);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            double* row = s_tab + 2 * loc[u];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(row + k, (double)v[u][k]);
+            const unsigned loc = __float_as_uint(r[u][0]);
+            if (loc < BIN_SEG_ROWS) {
+                double* row = s_tab + 2 * loc;
+                const double a = (double)r[u][1], b = (double)r[u][2], rho = (double)r[u][3];
+                atomicAdd(row, a);
+                atomicAdd(row + 1, b);
+                atomicAdd(row + 2, a * rho);
+                atomicAdd(row + 3, b * rho);
+            }
         }
     }
     __syncthreads();
@@ -436,29 +512,47 @@ static int raise_lds_limit(const void* kernel, std::atomic<bool>* done, int byte
 }
 
 constexpr int64_t BIN_MIN_POINTS = 65536;   // below this the per-segment zero and flush cost more than the atomics saved
-constexpr size_t BIN_COUNTER_BYTES = 4096;  // up to 1024 segment counters in front of the queues
+constexpr size_t BIN_COUNTER_BYTES = 65536;  // up to 16,384 queue counters in front of the queues
 
 static bool level_is_binned(int size) { return (unsigned)size > HG_LDS_MAX_ROWS; }
-static unsigned bin_capacity(int64_t P, int nseg) {
-    const int64_t even = ceil_div(4 * P, nseg);
-    const int64_t cap = even + even / 4 + 8192;
-    return (unsigned)(cap < 4 * P ? cap : 4 * P);
+// How a level's updates are queued.  A segment's share of the 4 P records is its share of the rows (rows are hit
+// uniformly; a table of 10,648 rows has a segment of 8,192 and one of 2,456).  slices = reduce workgroups per
+// segment (about BIN_SLICE_RECORDS records of a full segment each), nsub = queues per segment (at least 8), cap =
+// records per queue: 1.25 x its share, the padding of every run appended to it, a floor; a multiple of BIN_RUN so
+// that every queue starts on a line boundary.
+struct BinPlan {
+    int nseg, nsub, slices;
+    unsigned cap;
+};
+static BinPlan bin_plan(int64_t P, int size) {
+    BinPlan pl;
+    pl.nseg = (int)ceil_div(size, BIN_SEG_ROWS);
+    const int64_t seg_rows = size < BIN_SEG_ROWS ? size : BIN_SEG_ROWS;
+    const int64_t share = ceil_div(4 * P * seg_rows, (int64_t)size);
+    pl.slices = (int)ceil_div(share, BIN_SLICE_RECORDS);
+    pl.nsub = pl.slices > BIN_MIN_SUB ? pl.slices : BIN_MIN_SUB;
+    const int64_t wgs = ceil_div(ceil_div(P, BIN_PTS), pl.nsub);           // bin workgroups per queue
+    const int64_t sub_share = ceil_div(share, pl.nsub), pads = (BIN_RUN - 1) * wgs, most = 4 * wgs * BIN_PTS + pads;
+    int64_t cap = sub_share + sub_share / 4 + pads + 1024;
+    if (cap > most) cap = most;
+    pl.cap = (unsigned)ceil_div(cap, BIN_RUN) * BIN_RUN;
+    return pl;
 }
 
 size_t nerf::hashgrid_scatter_workspace_bytes(int64_t P, const int* sizes, int levels) {
-    if (P < BIN_MIN_POINTS || 4 * P >= (1ll << 31)) return 0;
-    size_t dwords = 0;
+    if (P < BIN_MIN_POINTS || 5 * P >= (1ll << 31)) return 0;
+    size_t records = 0;
     for (int l = 0; l < levels; ++l)
         if (level_is_binned(sizes[l])) {
-            const int nseg = (int)ceil_div(sizes[l], BIN_SEG_ROWS);
-            dwords += (size_t)5 * nseg * bin_capacity(P, nseg);
+            const BinPlan pl = bin_plan(P, sizes[l]);
+            records += (size_t)pl.nseg * pl.nsub * pl.cap;
         }
-    return dwords ? BIN_COUNTER_BYTES + 4 * dwords : 0;
+    return records ? BIN_COUNTER_BYTES + 16 * records : 0;
 }
 
-int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, const int* res, const int* sizes,
-                                  int levels, float* const* d_tables, void* workspace, size_t workspace_bytes,
-                                  hipStream_t stream) {
+int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, int64_t level_stride, const int* res,
+                                  const int* sizes, int levels, float* const* d_tables, void* workspace,
+                                  size_t workspace_bytes, hipStream_t stream) {
     static std::atomic<bool> lds_enabled[64], red_enabled[64];
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hashgrid_bwd_lds_kernel), lds_enabled,
                                  (int)(HG_LDS_MAX_ROWS * 2 * sizeof(double)))) return rc;
@@ -466,10 +560,12 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
     const bool binned = workspace && need;
     if (binned && workspace_bytes < need)
         return fail(NERF_EINVAL, "hashgrid_scatter: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+    if (binned && (size_t)workspace % 16)
+        return fail(NERF_EINVAL, "hashgrid_scatter: the workspace must be 16-byte aligned (128 for whole-line writes)");
     HashGradLevels lv;
     BinLevels bl;
     bl.n = 0;
-    bl.seg_first[0] = bl.wg_first[0] = 0;
+    bl.cnt_first[0] = bl.wg_first[0] = 0;
     long long q_off = 0;
     int big = 0;
     for (int l = 0; l < levels; ++l) {
@@ -478,22 +574,24 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
             // enough points per workgroup to pay for adding the whole table once per workgroup
             const int blocks = (int)(P / 2048 < 256 ? P / 2048 : 256);
             hipLaunchKernelGGL(hashgrid_bwd_lds_kernel, dim3(blocks), dim3(HG_LDS_THREADS), (size_t)sizes[l] * 2 * sizeof(double),
-                               stream, x, P, d_enc, d_tables[l], res[l], (unsigned)sizes[l], l, levels);
+                               stream, x, P, d_enc, d_tables[l], res[l], (unsigned)sizes[l], l, levels, level_stride);
             if (int rc = check_launch("hashgrid_scatter(lds)")) return rc;
         } else if (binned && level_is_binned(sizes[l])) {
-            const int j = bl.n++, nseg = (int)ceil_div(sizes[l], BIN_SEG_ROWS);
-            if (nseg > BIN_MAX_SEGS) return fail(NERF_EINVAL, "hashgrid_scatter: level %d has more than %d segments", l, BIN_MAX_SEGS);
+            const BinPlan pl = bin_plan(P, sizes[l]);
+            const int j = bl.n++;
+            if (pl.nseg > BIN_MAX_SEGS) return fail(NERF_EINVAL, "hashgrid_scatter: level %d has more than %d segments", l, BIN_MAX_SEGS);
             bl.table[j] = d_tables[l];
             bl.res[j] = res[l];
             bl.size[j] = (unsigned)sizes[l];
             bl.id[j] = l;
-            bl.nseg[j] = nseg;
-            bl.cap[j] = bin_capacity(P, nseg);
+            bl.nseg[j] = pl.nseg;
+            bl.nsub[j] = pl.nsub;
+            bl.slices[j] = pl.slices;
+            bl.cap[j] = pl.cap;
             bl.q_off[j] = q_off;
-            q_off += (long long)5 * nseg * bl.cap[j];
-            bl.slices[j] = (int)ceil_div(ceil_div(4 * P, nseg), BIN_SLICE_RECORDS);
-            bl.seg_first[j + 1] = bl.seg_first[j] + nseg;
-            bl.wg_first[j + 1] = bl.wg_first[j] + nseg * bl.slices[j];
+            q_off += (long long)pl.nseg * pl.nsub * pl.cap;
+            bl.cnt_first[j + 1] = bl.cnt_first[j] + pl.nseg * pl.nsub;
+            bl.wg_first[j + 1] = bl.wg_first[j] + pl.nseg * pl.slices;
         } else {
             lv.table[big] = d_tables[l];
             lv.res[big] = res[l];
@@ -503,15 +601,15 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
         }
     }
     if (bl.n) {
-        if ((size_t)bl.seg_first[bl.n] * 4 > BIN_COUNTER_BYTES) return fail(NERF_EINVAL, "hashgrid_scatter: too many segments");
+        if ((size_t)bl.cnt_first[bl.n] * 4 > BIN_COUNTER_BYTES) return fail(NERF_EINVAL, "hashgrid_scatter: too many queues");
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hashgrid_reduce_kernel), red_enabled,
                                      (int)((BIN_SEG_ROWS + 2) * 2 * sizeof(double)))) return rc;
         unsigned* counters = reinterpret_cast<unsigned*>(workspace);
-        float* queues = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + BIN_COUNTER_BYTES);
+        float4* queues = reinterpret_cast<float4*>(reinterpret_cast<char*>(workspace) + BIN_COUNTER_BYTES);
         if (hipMemsetAsync(counters, 0, BIN_COUNTER_BYTES, stream) != hipSuccess)
             return fail(NERF_ELAUNCH, "hashgrid_scatter: cannot clear the queue counters");
         hipLaunchKernelGGL(hashgrid_bin_kernel, dim3((unsigned)ceil_div(P, BIN_PTS)), dim3(BIN_PTS), 0, stream, x, P, d_enc,
-                           levels, bl, counters, queues);
+                           levels, level_stride, bl, counters, queues);
         if (int rc = check_launch("hashgrid_scatter(bin)")) return rc;
         hipLaunchKernelGGL(hashgrid_reduce_kernel, dim3(bl.wg_first[bl.n]), dim3(RED_THREADS),
                            (size_t)(BIN_SEG_ROWS + 2) * 2 * sizeof(double), stream, bl, counters, queues);
@@ -519,7 +617,7 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
     }
     if (big == 0) return NERF_OK;
     hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)ceil_div(4 * P, 256), big), dim3(256), 0, stream, x, P, d_enc, lv,
-                       levels);
+                       levels, level_stride);
     return check_launch("hashgrid_scatter");
 }
 
@@ -536,5 +634,5 @@ extern "C" int nerf_hashgrid_bwd(const float* x, int64_t P, const float* d_out, 
     NERF_REQUIRE(levels >= 1 && levels <= HG_MAX_LEVELS, "nerf_hashgrid_bwd: levels=%d outside [1,%d]", levels, HG_MAX_LEVELS);
     NERF_REQUIRE(P >= 0, "nerf_hashgrid_bwd: P=%lld", (long long)P);
     for (int l = 0; l < levels; ++l) NERF_REQUIRE(d_tables[l], "nerf_hashgrid_bwd: gradient table %d is null", l);
-    return launch_hashgrid_scatter(x, P, d_out, res, sizes, levels, d_tables, workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_hashgrid_scatter(x, P, d_out, 0, res, sizes, levels, d_tables, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -131,11 +131,13 @@ int launch_hashgrid_gather(const float* x, int64_t P, const float* const* tables
                            float* out, bool level_major, int64_t level_stride, hipStream_t stream);
 
 // d_tables[l][row][f] += corner weight * d_enc[p][2l + f] over all points and corners
-// (the backward of the hash-grid gather); defined with the encoder kernels.  With a workspace of
+// (the backward of the hash-grid gather); defined with the encoder kernels.  d_enc is row-major [P][2 * levels]
+// (level_stride 0) or level-major [levels][level_stride][2].  With a workspace of
 // hashgrid_scatter_workspace_bytes() the updates of the large tables are binned by table segment and summed
 // in LDS; without one (or when that size is 0: few points) every update is a float atomic on the table.
 size_t hashgrid_scatter_workspace_bytes(int64_t P, const int* sizes, int levels);
-int launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, const int* res, const int* sizes, int levels,
-                            float* const* d_tables, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, int64_t level_stride, const int* res,
+                            const int* sizes, int levels, float* const* d_tables, void* workspace, size_t workspace_bytes,
+                            hipStream_t stream);
 
 }  // namespace nerf

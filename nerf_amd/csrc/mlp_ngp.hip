@@ -43,7 +43,7 @@ constexpr int DYC = 0;      // [P32][64]
 constexpr int DRAW = 64;    // [P32][32]
 constexpr int DYD = 96;     // [P32][64]
 constexpr int DOUT4 = 160;  // [P32][4]
-constexpr int DENC = 164;   // [P32][32] gradient of the encoding, natural feature order
+constexpr int DENC = 164;   // [16][P32][2] gradient of the encoding, level-major like the encoding itself
 constexpr int PER_POINT2 = 196;
 }  // namespace nw
 
@@ -214,11 +214,13 @@ __global__ __launch_bounds__(256) void ngp_bwd_data_kernel(const float* __restri
     f32x16 de[1];
     zero_tiles<1>(de);
     dense<2, 1>(pk + np::B_D1, dyd, de, lane);   // register r = d feature (16h + r): this lane's own levels
-    // The table gradients are scattered by a second launch that lays lanes out for shared
-    // cache lines (launch_hashgrid_scatter); this lane holds d feature 16h + r in register r.
-    float4* denc = reinterpret_cast<float4*>(ws2 + ix.P32 * nw::DENC + ix.gp * 32 + 16 * h);
+    // The table gradients are scattered by further launches (launch_hashgrid_scatter), which walk the levels one
+    // after the other: level-major, so that each reads a contiguous run.  This lane holds d feature 16h + r in
+    // register r, i.e. levels 8h .. 8h+7; 32 consecutive lanes write 256 contiguous bytes per level.
+    float* denc = ws2 + ix.P32 * nw::DENC;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) denc[q] = make_float4(de[0][4 * q], de[0][4 * q + 1], de[0][4 * q + 2], de[0][4 * q + 3]);
+    for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<float2*>(denc + 2 * ((8 * h + j) * ix.P32 + ix.gp)) = make_float2(de[0][2 * j], de[0][2 * j + 1]);
 }
 
 }  // namespace nerf
@@ -332,7 +334,7 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
         p.k_first = 1;
         parts.part[n++] = p;
     }
-    if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st)) return rc;
+    if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, P32, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st)) return rc;
     parts.n = n;
     if (int rc = launch_wgrad(parts, P32, st)) return rc;
     SkinnyPart c2{DOUT4, HC, grads[6], grads[7], 4, 64, 1, 3, 64};                                           // fc_color.2
