@@ -81,7 +81,7 @@ def ngp_loss(out, gt):
     return torch.nn.functional.mse_loss(out["rgb"], gt) + 0.05 * (1.0 - out["weights"].sum(dim=-1)).abs().mean()
 
 
-def build_step(kind, rank, rays, dev, chunk_rays):
+def build_step(kind, rank, rays, dev, chunk_rays, capturable=False):
     """One training step of the vanilla (coarse + fine 8x256 MLPs, 64 + 128 samples) or hash-grid workload:
     fused ray generation + stratified sampling, chunked forward/backward with the gradients in flat buckets
     (their cross-rank sum starts under the last chunk's backward), fused Adam.  Returns (step, model)."""
@@ -99,7 +99,7 @@ def build_step(kind, rank, rays, dev, chunk_rays):
         model = FastNGPNeRF().to(dev)
         buckets = GradBuckets([list(model.hash_encoder.parameters()),
                                [p for n, p in model.named_parameters() if not n.startswith("hash_encoder")]], overlap=OVERLAP)
-        opt = FusedAdam(buckets.parameters(), lr=1e-2, eps=1e-15)
+        opt = FusedAdam(buckets.parameters(), lr=1e-2, eps=1e-15, capturable=capturable)
         c2w = c2w.clone()
         c2w[:, 3] = c2w[:, 3] / 4.03
         z_lin = torch.linspace(NGP_NEAR, NGP_FAR, N_COARSE).to(dev)
@@ -125,6 +125,22 @@ def build_step(kind, rank, rays, dev, chunk_rays):
         return loss
 
     return step, model
+
+
+def build_ngp_step(rank, rays, dev, chunk_rays, world, use_graph):
+    """The hash-grid step; with use_graph captured into a HIP graph and replayed where that applies: one GPU (no
+    collective inside the step) and one ray chunk.  Returns (step, model, info for the result's config)."""
+    if use_graph and world == 1 and (chunk_rays is None or chunk_rays >= rays) and rays <= 65536:
+        try:
+            from nerf_amd.graph import GraphedStep
+            eager, model = build_step("ngp", rank, rays, dev, chunk_rays, capturable=True)
+            return GraphedStep(eager, warmup=3), model, {"hip_graph": True}
+        except Exception as e:   # the same kernels run eagerly; the line says so
+            torch.cuda.synchronize()
+            step, model = build_step("ngp", rank, rays, dev, chunk_rays)
+            return step, model, {"hip_graph": False, "hip_graph_error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    step, model = build_step("ngp", rank, rays, dev, chunk_rays)
+    return step, model, {"hip_graph": False}
 
 
 def timed_steps(step, steps, warmup, world, dev):
@@ -174,20 +190,24 @@ def gpu_main(args):
     # one GPU: the 4096-ray batch the headline metric is quoted on; data parallel: 65,536 rays per GPU
     rays = args.rays if args.rays else (RAYS_SINGLE if world == 1 else RAYS_DP)
     chunk = args.chunk_rays
-    step, model = build_step(args.model, rank, rays, dev, chunk)
+    graph_info = {}
+    if args.model == "ngp":
+        step, model, graph_info = build_ngp_step(rank, rays, dev, chunk, world, args.graph)
+    else:
+        step, model = build_step(args.model, rank, rays, dev, chunk)
     dt, final_loss = timed_steps(step, args.steps, args.warmup, world, dev)
     secondary = None
     if args.model == "vanilla" and not args.no_secondary:
         # the hash-grid configuration, same camera and batch size, as a second result in the same line
         del step
         torch.cuda.empty_cache()
-        step2, ngp = build_step("ngp", rank, rays, dev, chunk)
+        step2, ngp, graph2 = build_ngp_step(rank, rays, dev, chunk, world, args.graph)
         n2 = max(5, args.steps)
         dt2, loss2 = timed_steps(step2, n2, 3, world, dev)
         if rank == 0:
             secondary = {"metric": "rays/sec fwd+bwd (hash-grid model, 64 samples)", "value": world * rays * n2 / dt2,
                          "unit": "rays/s", "n_gpus": world, "steps": n2, "ms_per_step": 1e3 * dt2 / n2, "dtype": "f32",
-                         "config": {"workload": NGP_WORKLOAD % rays, "rays_per_gpu": rays, "final_loss": loss2},
+                         "config": {"workload": NGP_WORKLOAD % rays, "rays_per_gpu": rays, "final_loss": loss2, **graph2},
                          "roofline": ngp_roofline(ngp, min(rays, 65536), dev)}
 
     result = None
@@ -198,7 +218,7 @@ def gpu_main(args):
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": NGP_WORKLOAD % rays, "rays_per_gpu": rays, "parallelism": "ray-sharded dp%d" % world,
-                       "final_loss": final_loss},
+                       "final_loss": final_loss, **graph_info},
             "roofline": ngp_roofline(model, min(rays, 65536), dev),
         }
     elif rank == 0:
@@ -414,6 +434,9 @@ def main():
                     help="vanilla = the headline workload; ngp = the hash-grid variant (secondary line)")
     ap.add_argument("--cpu-rays", type=int, default=1024, help="ray sample of the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the hash-grid step into a HIP graph and replay it (one GPU, one ray chunk); measured: "
+                         "0.984 against 0.992 ms per 4096-ray step, the step is not bound by the host")
     args = ap.parse_args()
     if os.environ.get("NERF_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack and exit after that many seconds
         import faulthandler

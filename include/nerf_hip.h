@@ -243,6 +243,17 @@ int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, i
 int nerf_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, int64_t step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, void* stream);
+/* The same step with the step count in device memory, for a training step that is captured into a
+ * HIP graph and replayed (torch.optim.Adam(capturable=True)): a count passed by value would be
+ * frozen into the graph.  step_state: 4 device floats, [0] = steps taken so far (0 before the first
+ * step; integers are exact in a float up to 2^24 steps).  Every call adds 1 to it (a one-thread
+ * launch in front of the update, which also leaves sqrt(1 - beta2^step) in [1] and
+ * -lr / (1 - beta1^step) in [2]) and applies the update for that step.  Neither the host nor the
+ * call reads anything back. */
+int nerf_adam_step_capturable(int count, float* const* params, const float* const* grads,
+                              float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                              float* step_state, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, void* stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) with the 2-norm (src/train_nerf.py:165):
  * total = the norm of all gradients together, every gradient is multiplied by

@@ -49,6 +49,7 @@ SIGNATURES = {
     "nerf_mlp_ngp_fwd": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_mlp_ngp_bwd": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "nerf_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
+    "nerf_adam_step_capturable": (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
     "nerf_clip_grad_norm_workspace_floats": (C.c_size_t, [_I, _P]),
     "nerf_clip_grad_norm": (_I, [_I, _P, _P, _F, _P, _P, _P]),
     "nerf_clip_grad_norm_static": (_I, [_I, _P, _P, _F, _P, _P]),

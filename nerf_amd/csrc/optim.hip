@@ -37,8 +37,14 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p + neg_step * (m / denom);
 }
 
+// dev_scalars: null, or the step state in device memory that adam_advance_kernel has just brought up to date
+// ([1] = sqrt(bias2), [2] = -lr / bias1), used in place of the two kernel arguments.
 __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float b1m, float b2, float b2m, float bias2_sqrt,
-                                                   float eps, float neg_step, float wd) {
+                                                   float eps, float neg_step, float wd, const float* __restrict__ dev_scalars) {
+    if (dev_scalars) {
+        bias2_sqrt = dev_scalars[1];
+        neg_step = dev_scalars[2];
+    }
     int k = 0;
     while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
     const long long base = (long long)(blockIdx.x - t.first_block[k]) * ADAM_CHUNK;
@@ -89,6 +95,18 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float b1m, flo
             for (long long e = i; e < i + 4 && e < n; ++e) adam_one(p[e], g[e], m[e], v[e], b1m, b2, b2m, bias2_sqrt, eps, neg_step, wd);
         }
     }
+}
+
+// The step count of an optimiser whose launches are replayed from a HIP graph cannot be a kernel argument (it
+// would be frozen into the graph): state[0] holds it in device memory.  One thread advances it and derives the two
+// step-dependent scalars the way the host does for nerf_adam_step (in double, rounded to float).
+__global__ void adam_advance_kernel(float* __restrict__ state, float lr, float beta1, float beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double step = (double)state[0] + 1.0;
+    const double bias1 = 1.0 - pow((double)beta1, step), bias2 = 1.0 - pow((double)beta2, step);
+    state[0] = (float)step;
+    state[1] = (float)sqrt(bias2);
+    state[2] = (float)(-((double)lr / bias1));
 }
 
 // ---------------------------------------------------------------------------
@@ -251,24 +269,29 @@ static int clip_static_scratch(float** out) {
 
 using namespace nerf;
 
-extern "C" int nerf_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
-                              float* const* exp_avg_sq, const int64_t* numel, int64_t step, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, void* stream) {
-    if (count == 0) return NERF_OK;
-    NERF_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, "nerf_adam_step: null pointer");
-    NERF_REQUIRE(count > 0 && step >= 1, "nerf_adam_step: count=%d step=%lld", count, (long long)step);
+// step_state: null (the step count is `step`), or 4 floats in device memory whose first holds the count of steps taken.
+static int adam_run(const char* who, int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, int64_t step, float* step_state, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, hipStream_t stream) {
     // the scalars as torch computes them (Python floats = double), rounded to float where a tensor op consumes them
-    const double bias1 = 1.0 - pow((double)beta1, (double)step), bias2 = 1.0 - pow((double)beta2, (double)step);
     const float b1m = (float)(1.0 - (double)beta1), b2m = (float)(1.0 - (double)beta2);
-    const float bias2_sqrt = (float)sqrt(bias2), neg_step = (float)(-((double)lr / bias1));
+    float bias2_sqrt = 1.0f, neg_step = 0.0f;
+    if (step_state) {
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, stream, step_state, lr, beta1, beta2);
+        if (int rc = check_launch(who)) return rc;
+    } else {
+        const double bias1 = 1.0 - pow((double)beta1, (double)step), bias2 = 1.0 - pow((double)beta2, (double)step);
+        bias2_sqrt = (float)sqrt(bias2);
+        neg_step = (float)(-((double)lr / bias1));
+    }
     for (int k = 0; k < count;) {   // batches of up to ADAM_MAX_TENSORS non-empty tensors; k carries over
         AdamTensors t;
         t.count = 0;
         int blocks = 0;
         for (; k < count && t.count < ADAM_MAX_TENSORS; ++k) {
-            NERF_REQUIRE(numel[k] >= 0, "nerf_adam_step: tensor %d has %lld elements", k, (long long)numel[k]);
+            NERF_REQUIRE(numel[k] >= 0, "%s: tensor %d has %lld elements", who, k, (long long)numel[k]);
             if (numel[k] == 0) continue;
-            NERF_REQUIRE(params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k], "nerf_adam_step: tensor %d has a null pointer", k);
+            NERF_REQUIRE(params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k], "%s: tensor %d has a null pointer", who, k);
             const int c = t.count++;
             t.p[c] = params[k]; t.g[c] = grads[k]; t.m[c] = exp_avg[k]; t.v[c] = exp_avg_sq[k]; t.n[c] = numel[k];
             t.first_block[c] = blocks;
@@ -276,11 +299,31 @@ extern "C" int nerf_adam_step(int count, float* const* params, const float* cons
         }
         if (t.count == 0) continue;
         t.first_block[t.count] = blocks;
-        hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, b1m, beta2, b2m, bias2_sqrt, eps,
-                           neg_step, weight_decay);
-        if (int rc = check_launch("nerf_adam_step")) return rc;
+        hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, t, b1m, beta2, b2m, bias2_sqrt, eps, neg_step,
+                           weight_decay, (const float*)step_state);
+        if (int rc = check_launch(who)) return rc;
     }
     return NERF_OK;
+}
+
+extern "C" int nerf_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                              float* const* exp_avg_sq, const int64_t* numel, int64_t step, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, void* stream) {
+    if (count == 0) return NERF_OK;
+    NERF_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, "nerf_adam_step: null pointer");
+    NERF_REQUIRE(count > 0 && step >= 1, "nerf_adam_step: count=%d step=%lld", count, (long long)step);
+    return adam_run("nerf_adam_step", count, params, grads, exp_avg, exp_avg_sq, numel, step, nullptr, lr, beta1, beta2, eps,
+                    weight_decay, (hipStream_t)stream);
+}
+
+extern "C" int nerf_adam_step_capturable(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                                         float* const* exp_avg_sq, const int64_t* numel, float* step_state, float lr,
+                                         float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    NERF_REQUIRE(step_state, "nerf_adam_step_capturable: null step state");
+    NERF_REQUIRE(count >= 0 && (count == 0 || (params && grads && exp_avg && exp_avg_sq && numel)),
+                 "nerf_adam_step_capturable: null pointer");
+    return adam_run("nerf_adam_step_capturable", count, params, grads, exp_avg, exp_avg_sq, numel, 0, step_state, lr, beta1,
+                    beta2, eps, weight_decay, (hipStream_t)stream);
 }
 
 extern "C" size_t nerf_clip_grad_norm_workspace_floats(int count, const int64_t* numel) {

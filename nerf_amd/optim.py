@@ -7,6 +7,11 @@ loops use, same update rule, and a ``state_dict`` with torch's keys
 (``step`` / ``exp_avg`` / ``exp_avg_sq``), so checkpoints move both ways.  ``weight_decay`` is torch's L2
 form (src/train_nerf_llff.py:82, src/train_nerf_skow.py:47 use 1e-6); amsgrad and maximize are
 not implemented and raise.  ``clip_grad_norm_`` (src/train_nerf.py:165) lives in ``nerf_amd.ops``.
+
+``capturable=True`` (torch's name for it) keeps the step count in device memory, so that a whole training
+step -- this optimiser's launch included -- can be captured into a HIP graph and replayed
+(``nerf_amd.graph.GraphedStep``): ``state[p]["step"]`` is then a float32 scalar on the GPU, as with
+``torch.optim.Adam(capturable=True)``, shared by the parameters of a group.
 """
 from __future__ import annotations
 
@@ -19,13 +24,35 @@ from . import _lib as L
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 amsgrad: bool = False, maximize: bool = False):
+                 amsgrad: bool = False, maximize: bool = False, capturable: bool = False):
         if amsgrad or maximize:
             raise NotImplementedError("FusedAdam implements Adam without amsgrad or maximize")
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False,
-                                      maximize=False))
+                                      maximize=False, capturable=bool(capturable)))
+        self._dev_state = {}   # capturable groups: index -> 4 device floats, [0] = steps taken
+
+    def _capturable_state(self, gi: int, ps) -> torch.Tensor:
+        """The group's step state in device memory; every parameter's ``state["step"]`` is the same 0-d view of
+        its first float.  Built on the first step (and after ``load_state_dict``) from the steps the states hold."""
+        entry = self._dev_state.get(gi)
+        if entry is None:
+            steps = {float(self.state[p]["step"]) for p in ps} or {0.0}
+            if len(steps) != 1:
+                raise L.NerfHipError("FusedAdam(capturable=True) needs one step count per parameter group")
+            dev = torch.zeros(4, device=ps[0].device, dtype=torch.float32)
+            dev[0] = steps.pop()
+            entry = self._dev_state[gi] = (dev, dev[0])
+        dev, view = entry
+        for p in ps:
+            if self.state[p]["step"] is not view:
+                self.state[p]["step"] = view
+        return dev
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._dev_state = {}   # rebuilt from the loaded step counts on the next step
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -33,7 +60,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
@@ -48,6 +75,18 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if group.get("capturable", False):
+                # one launch pair for the group, nothing read back, no host-side step count
+                dev = self._capturable_state(gi, ps)
+                n = len(ps)
+                numel = (C.c_int64 * n)(*[p.numel() for p in ps])
+                L.check(L.lib().nerf_adam_step_capturable(
+                    n, L.ptr_array(ps), L.ptr_array([L.f32c(p.grad) for p in ps]),
+                    L.ptr_array([self.state[p]["exp_avg"] for p in ps]),
+                    L.ptr_array([self.state[p]["exp_avg_sq"] for p in ps]), numel, L.ptr(dev), group["lr"],
+                    group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
+                    L.stream_of(ps[0])), "nerf_adam_step_capturable")
+                continue
             # parameters of one group share the step count unless states were loaded piecemeal
             by_step = {}
             for p in ps:

@@ -115,7 +115,8 @@ def workspace_bytes_per_ray(model, n_samples: int, fine_model=None, n_importance
 def train_step(model, rays_o, rays_d, target, near: float, far: float, n_samples: int, *, loss_fn=None,
                chunk_rays: Optional[int] = None, workspace_budget: int = 32 << 30, buckets=None,
                grad_scale: Optional[float] = None, t_rand: Optional[torch.Tensor] = None,
-               u_fine: Optional[torch.Tensor] = None, samples=None, **render_kw) -> torch.Tensor:
+               u_fine: Optional[torch.Tensor] = None, samples=None, z_lin: Optional[torch.Tensor] = None,
+               **render_kw) -> torch.Tensor:
     """Forward + backward of one training step over R rays, in ray chunks, gradients accumulated.
 
     The reference bounds memory with a chunk loop over points inside ``render_image``
@@ -129,6 +130,8 @@ def train_step(model, rays_o, rays_d, target, near: float, far: float, n_samples
     ``nerf_amd.dist.GradBuckets``) receives the gradients in its flat buffers and overlaps the cross-rank
     sum with the last chunk's backward; without it the gradients accumulate into ``p.grad`` (zero them
     first).  The optimiser step is the caller's.  Returns the detached loss (0-d tensor).
+    ``z_lin`` [n_samples]: the unperturbed depths, already on the GPU (default: computed on the host as the
+    reference does and copied over -- a step that is to be captured into a HIP graph must pass them).
     """
     from .dist import accumulate_step
     R = rays_o.shape[0]
@@ -137,7 +140,8 @@ def train_step(model, rays_o, rays_d, target, near: float, far: float, n_samples
         per_ray = workspace_bytes_per_ray(model, n_samples, render_kw.get("fine_model"), render_kw.get("n_importance", 0))
         chunk_rays = 1 << max(0, (workspace_budget // max(per_ray, 1)).bit_length() - 1)
     chunk_rays = max(1, min(int(chunk_rays), R))
-    z_lin = _linspace(near, far, n_samples, rays_o.device) if samples is None else None
+    if z_lin is None and samples is None:
+        z_lin = _linspace(near, far, n_samples, rays_o.device)
 
     def loss_of_chunk(lo, hi):
         out = render_rays(model, rays_o[lo:hi], rays_d[lo:hi], near, far, n_samples,
