@@ -91,13 +91,18 @@ __device__ __forceinline__ void store16(float* __restrict__ dst, const f32x16& v
 }
 
 template <bool SAVE>
-__global__ __launch_bounds__(256) void ngp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
+__global__ __launch_bounds__(256, 4) void ngp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                       int dirs_div, long long P,
                                                       const float* __restrict__ pk, float* __restrict__ rgb,
                                                       float* __restrict__ sigma, float* __restrict__ ws) {
+    // a wave's 32 x 64 (or 32 x 32) block of a saved matrix is contiguous in memory: its register tiles go through a
+    // per-wave LDS transposition buffer and leave as whole rows, 16 bytes per lane (stored straight from the register
+    // layout an instruction writes 64 pieces of 16 bytes, 256 bytes apart)
+    __shared__ __attribute__((aligned(16))) float s_tile[4][TILE_LDS_FLOATS];
     NgpIdx ix;
     if (!ngp_index(P, ix)) return;
     const int lane = ix.lane, h = ix.h;
+    const TileBuf tb = tile_buf(s_tile[threadIdx.x >> 6], lane);
     // ---- hash encoding: levels 8h .. 8h+7 of this lane's point, gathered level by level by the launch before
     // this one (enc: [16][P32][2]); 32 consecutive lanes read 256 contiguous bytes per level
     f32x16 e[1];
@@ -113,12 +118,15 @@ __global__ __launch_bounds__(256) void ngp_fwd_kernel(const float* __restrict__ 
     fill_rows<2>(hd, pk + np::S_BD1, h);
     dense<1, 2>(pk + np::F_D1, e, hd, lane);
     relu_tiles<2>(hd);
+    // every saved matrix leaves right after it is formed, under the layers that follow
+    if (SAVE) save_tiles<2>(tb, ws + ix.P32 * nw::HD + ix.tile * (32 * 64), 64, hd);
     f32x16 cin[2];   // [raw | pe(dir)]
     {
         f32x16 raw[1];
         fill_rows<1>(raw, pk + np::S_BD2, h);
         dense<2, 1>(pk + np::F_D2, hd, raw, lane);
         cin[0] = raw[0];
+        if (SAVE) save_tiles<1>(tb, ws + ix.P32 * nw::RAW + ix.tile * (32 * 32), 32, raw);
     }
     if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(cin[0][0] + 1.5f);   // row 0 lives in lane half 0, register 0  (:91-92)
     // ---- view direction: normalise, encode with 4 bands (:98-99); zeros when no directions are given (:100-103)
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(256) void ngp_fwd_kernel(const float* __restrict__ 
             zero_tiles<1>(de);
         }
         cin[1] = de[0];
+        if (SAVE) save_tiles<1>(tb, ws + ix.P32 * nw::DE + ix.tile * (32 * 32), 32, de);
     }
     // ---- colour MLP: sigmoid(W4 relu(W3 [feat | pe] + Wskip feat + b3) + b4)   (:105-108)
     f32x16 hc[2];
@@ -141,13 +150,7 @@ __global__ __launch_bounds__(256) void ngp_fwd_kernel(const float* __restrict__ 
     dense<2, 2>(pk + np::F_C1, cin, hc, lane);
     relu_tiles<2>(hc);
     if (SAVE) {
-        store_row<2>(ws + ix.P32 * nw::HD + ix.gp * 64, hd, h, true);
-        store_row<2>(ws + ix.P32 * nw::HC + ix.gp * 64, hc, h, true);
-        f32x16 t1[1];
-        t1[0] = cin[0];
-        store_row<1>(ws + ix.P32 * nw::RAW + ix.gp * 32, t1, h, true);
-        t1[0] = cin[1];
-        store_row<1>(ws + ix.P32 * nw::DE + ix.gp * 32, t1, h, true);
+        save_tiles<2>(tb, ws + ix.P32 * nw::HC + ix.tile * (32 * 64), 64, hc);
         unsigned* mask = reinterpret_cast<unsigned*>(ws + ix.P32 * nw::MASK) + ix.tile * 128 + lane;
         mask[0] = relu_bits2(hd);
         mask[64] = relu_bits2(hc);
@@ -160,15 +163,17 @@ __global__ __launch_bounds__(256) void ngp_fwd_kernel(const float* __restrict__ 
 }
 
 // Backward-data chain ending in the hash-table scatter.
-__global__ __launch_bounds__(256) void ngp_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ d_rgb,
+__global__ __launch_bounds__(256, 4) void ngp_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ d_rgb,
                                                            const float* __restrict__ d_sigma, long long P,
                                                            const float* __restrict__ pk,
                                                            const float* __restrict__ rgb,
                                                            const float* __restrict__ sigma,
                                                            const float* __restrict__ ws, float* __restrict__ ws2) {
+    __shared__ __attribute__((aligned(16))) float s_tile[4][TILE_LDS_FLOATS];   // as in the forward kernel
     NgpIdx ix;
     if (!ngp_index(P, ix)) return;
     const int lane = ix.lane, h = ix.h;
+    const TileBuf tb = tile_buf(s_tile[threadIdx.x >> 6], lane);
     const unsigned* mask = reinterpret_cast<const unsigned*>(ws + ix.P32 * nw::MASK) + ix.tile * 128 + lane;
     float dpre[3], dps = 0.0f;
 #pragma unroll
@@ -199,18 +204,18 @@ __global__ __launch_bounds__(256) void ngp_bwd_data_kernel(const float* __restri
             dyc[t][4 * q + 3] = s.w;
         }
     apply_bits2(dyc, mask[64]);
-    store_row<2>(ws2 + ix.P32 * nw::DYC + ix.gp * 64, dyc, h, true);
+    save_tiles<2>(tb, ws2 + ix.P32 * nw::DYC + ix.tile * (32 * 64), 64, dyc);
     // d raw: features through (W3 + Wskip)^T, density through softplus'
     f32x16 draw[1];
     zero_tiles<1>(draw);
     dense<2, 1>(pk + np::B_C1, dyc, draw, lane);
     if (h == 0) draw[0][0] += dps;
-    store_row<1>(ws2 + ix.P32 * nw::DRAW + ix.gp * 32, draw, h, true);
+    save_tiles<1>(tb, ws2 + ix.P32 * nw::DRAW + ix.tile * (32 * 32), 32, draw);
     f32x16 dyd[2];
     zero_tiles<2>(dyd);
     dense<1, 2>(pk + np::B_D2, draw, dyd, lane);
     apply_bits2(dyd, mask[0]);
-    store_row<2>(ws2 + ix.P32 * nw::DYD + ix.gp * 64, dyd, h, true);
+    save_tiles<2>(tb, ws2 + ix.P32 * nw::DYD + ix.tile * (32 * 64), 64, dyd);
     f32x16 de[1];
     zero_tiles<1>(de);
     dense<2, 1>(pk + np::B_D1, dyd, de, lane);   // register r = d feature (16h + r): this lane's own levels
