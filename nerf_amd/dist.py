@@ -73,13 +73,55 @@ class GradBuckets:
             views = []
             for p, o in zip(b, starts):
                 views.append(flat[o:o + p.numel()].view_as(p))
-                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, bi=bi: self._delivered(bi)))
+                self._hooks.append(p.register_post_accumulate_grad_hook(
+                    lambda _p, bi=bi, pi=len(views) - 1: self._delivered(bi, pi)))
             self.flats.append(flat)
             self.views.append(views)
         self._armed = False
-        self._missing = [0] * len(self.buckets)
+        self._got: List[set] = [set() for _ in self.buckets]   # parameters of the bucket whose gradient is complete
+        self._pending = [0] * len(self.buckets)                # fused-op calls forwarded whose backward is still to come
         self._work: List[Optional[object]] = [None] * len(self.buckets)
         self._sent = [False] * len(self.buckets)
+        # parameter storage -> (bucket, index in bucket, view): the gradient sink of the fused ops (below)
+        self._slot = {p.data_ptr(): (bi, pi, v) for bi, (b, views) in enumerate(zip(self.buckets, self.views))
+                      for pi, (p, v) in enumerate(zip(b, views)) if p.numel()}
+
+    # ---- gradient sink of the fused MLP ops (nerf_amd.ops.grad_sink): their backward kernels accumulate straight
+    # into the views instead of handing autograd a gradient to add.
+    def targets(self, params) -> Optional[List[torch.Tensor]]:
+        """The views to accumulate the gradients of ``params`` into, or None unless every one of them lives here
+        with its view installed as ``p.grad`` (``zero_grad()`` does that and zeroes them)."""
+        out = []
+        for p in params:
+            slot = self._slot.get(p.data_ptr()) if p.numel() else None
+            g = p.grad
+            if slot is None or g is None or g.data_ptr() != slot[2].data_ptr() or g.shape != p.shape:
+                return None
+            out.append(slot[2])
+        return out
+
+    def _buckets_of(self, params) -> set:
+        return {self._slot[p.data_ptr()][0] for p in params if p.numel() and p.data_ptr() in self._slot}
+
+    def expect(self, params) -> None:
+        """A fused op has run forward on ``params`` and will deliver their gradients through ``done``: a bucket is
+        not complete before every such call has (one model may serve two passes of a render)."""
+        for bi in self._buckets_of(params):
+            self._pending[bi] += 1
+
+    def done(self, params) -> None:
+        """The kernels that accumulate into the views of ``params`` are enqueued -- what the post-accumulate hooks
+        report when autograd does the accumulation."""
+        touched = self._buckets_of(params)
+        for bi in touched:
+            self._pending[bi] = max(0, self._pending[bi] - 1)
+        if self._armed:
+            for p in params:
+                slot = self._slot.get(p.data_ptr()) if p.numel() else None
+                if slot is not None:
+                    self._got[slot[0]].add(slot[1])
+            for bi in touched:
+                self._maybe_send(bi)
 
     @property
     def grad_scale(self) -> float:
@@ -93,13 +135,15 @@ class GradBuckets:
                 if p.grad is not v:
                     p.grad = v
         self._armed = False
+        self._pending = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._sent = [False] * len(self.buckets)
 
     def arm(self) -> None:
         """Announce that the next backward pass completes the gradients of this step."""
         self._armed = True
-        self._missing = [len(b) for b in self.buckets]
+        # empty parameters have nothing to wait for
+        self._got = [{pi for pi, p in enumerate(b) if p.numel() == 0} for b in self.buckets]
 
     def _send(self, bi: int) -> None:
         self._sent[bi] = True
@@ -111,11 +155,15 @@ class GradBuckets:
                 torch.cuda.current_stream(flat.device).synchronize()
             self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def _delivered(self, bi: int) -> None:
-        if not self._armed or not self.overlap:
+    def _delivered(self, bi: int, pi: int) -> None:
+        if not self._armed:
             return
-        self._missing[bi] -= 1
-        if self._missing[bi] == 0 and not self._sent[bi]:
+        self._got[bi].add(pi)
+        self._maybe_send(bi)
+
+    def _maybe_send(self, bi: int) -> None:
+        if (self._armed and self.overlap and not self._sent[bi] and self._pending[bi] == 0
+                and len(self._got[bi]) == len(self.buckets[bi])):
             self._send(bi)
 
     def finish(self) -> None:
@@ -149,18 +197,26 @@ def accumulate_step(n_items: int, chunk: int, loss_of_chunk: Callable[[int, int]
     gradients land in its flat buffers and the cross-rank sum starts under the last chunk's backward;
     ``grad_scale`` defaults to 1 / world size.  Returns the detached total loss (a 0-d tensor, no host sync).
     """
+    import contextlib
     if grad_scale is None:
         grad_scale = buckets.grad_scale if buckets is not None else 1.0
+    sink = contextlib.nullcontext()
     if buckets is not None:
         buckets.zero_grad()
+        if any(f.is_cuda for f in buckets.flats):
+            # the fused ops' backward kernels accumulate straight into the flat buffers (no per-parameter
+            # zero-fill and add by autograd)
+            from . import ops
+            sink = ops.grad_sink(buckets)
     total = None
     spans = [(lo, min(lo + chunk, n_items)) for lo in range(0, n_items, chunk)]
-    for k, (lo, hi) in enumerate(spans):
-        loss = loss_of_chunk(lo, hi) * ((hi - lo) / n_items)
-        if buckets is not None and k == len(spans) - 1:
-            buckets.arm()
-        (loss * grad_scale if grad_scale != 1.0 else loss).backward()
-        total = loss.detach() if total is None else total + loss.detach()
+    with sink:
+        for k, (lo, hi) in enumerate(spans):
+            loss = loss_of_chunk(lo, hi) * ((hi - lo) / n_items)
+            if buckets is not None and k == len(spans) - 1:
+                buckets.arm()
+            (loss * grad_scale if grad_scale != 1.0 else loss).backward()
+            total = loss.detach() if total is None else total + loss.detach()
     if buckets is not None:
         buckets.finish()
     return total

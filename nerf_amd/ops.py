@@ -316,6 +316,56 @@ def zero_grads_like(shapes, device):
     return [flat[o:o + n].view(s) for s, n, o in zip(shapes, sizes, starts)]
 
 
+# Where the parameter gradients of the fused MLPs go.  By default backward() returns them as new tensors and
+# autograd adds them to p.grad: one zero-fill and one add per parameter and backward pass (for the hash-grid model
+# 25 launches and 250 MB of traffic per step, an eighth of a 4096-ray step).  The kernels accumulate with atomics
+# anyway, so while a sink is installed (grad_sink(...): accumulate_step does it for its GradBuckets) they
+# accumulate straight into the tensors the sink names -- the buckets' p.grad views -- and autograd receives no
+# gradient for those parameters; the sink is told afterwards, in place of the post-accumulate hooks.
+_GRAD_SINK = None
+
+
+class grad_sink:
+    """``with grad_sink(sink):`` -- ``sink.targets(params)`` returns the tensors to accumulate the gradients of
+    ``params`` into (same shapes, float32, contiguous, zeroed by the sink's owner when a step starts) or None to
+    decline; ``sink.expect(params)`` is called from the forward pass of every op call that will deliver through the
+    sink, ``sink.done(params)`` once that call's backward kernels are enqueued."""
+
+    def __init__(self, sink):
+        self.sink = sink
+
+    def __enter__(self):
+        global _GRAD_SINK
+        self.prev, _GRAD_SINK = _GRAD_SINK, self.sink
+        return self
+
+    def __exit__(self, *exc):
+        global _GRAD_SINK
+        _GRAD_SINK = self.prev
+        return False
+
+
+def _grad_expect(params):
+    """Forward of a fused op in training mode: tell the sink, if it takes these parameters, that one backward
+    call will deliver their gradients."""
+    sink = _GRAD_SINK
+    if sink is not None and sink.targets(params) is not None:
+        sink.expect(params)
+        return True
+    return False
+
+
+def _grad_targets(params, shapes, device, expected):
+    """(tensors the backward kernels accumulate into, the sink that owns them or None).  Only a call whose forward
+    announced itself to the sink delivers through it."""
+    sink = _GRAD_SINK
+    if expected and sink is not None:
+        targets = sink.targets(params)
+        if targets is not None:
+            return targets, sink
+    return zero_grads_like(shapes, device), None
+
+
 class _VanillaMLP(torch.autograd.Function):
     """Fused 8x256 NeRF MLP: (x [P,3], dirs, 24 parameters) -> (rgb [P,3], sigma [P,1]).
 
@@ -341,6 +391,8 @@ class _VanillaMLP(torch.autograd.Function):
         if train:
             ctx.save_for_backward(packed, rgb, sigma, ws)
             ctx.meta = (P, bool(skip_h_first), [p.shape for p in params])
+            ctx.params = params
+            ctx.expected = P > 0 and _grad_expect(params)
         ctx.set_materialize_grads(False)
         return rgb, sigma
 
@@ -349,12 +401,15 @@ class _VanillaMLP(torch.autograd.Function):
         packed, rgb, sigma, ws = ctx.saved_tensors
         P, skip, shapes = ctx.meta
         dev = rgb.device
-        grads = zero_grads_like(shapes, dev)
         if P == 0:
-            return (None, None, None, None, None, *grads)
+            return (None, None, None, None, None, *zero_grads_like(shapes, dev))
+        grads, sink = _grad_targets(ctx.params, shapes, dev, ctx.expected)
         d_rgb = L.f32c(d_rgb) if d_rgb is not None else torch.zeros(P, 3, device=dev)
         d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, 1, device=dev)
         vanilla_bwd_raw(d_rgb, d_sigma, packed, rgb, sigma, ws, vanilla_ws2(P, dev), skip, grads)
+        if sink is not None:
+            sink.done(ctx.params)
+            return (None,) * (5 + len(grads))
         return (None, None, None, None, None, *grads)
 
 
@@ -404,6 +459,8 @@ class _NgpMLP(torch.autograd.Function):
         if train:
             ctx.save_for_backward(xc, packed, rgb, sigma, ws)
             ctx.meta = (P, list(res), sizes, [t.shape for t in tensors])
+            ctx.params = tensors
+            ctx.expected = P > 0 and _grad_expect(tensors)
         ctx.set_materialize_grads(False)
         return rgb, sigma
 
@@ -413,9 +470,9 @@ class _NgpMLP(torch.autograd.Function):
         P, res, sizes, shapes = ctx.meta
         lib = L.lib()
         dev = rgb.device
-        grads = zero_grads_like(shapes, dev)
         if P == 0:
-            return (None, None, None, None, None, *grads)
+            return (None, None, None, None, None, *zero_grads_like(shapes, dev))
+        grads, sink = _grad_targets(ctx.params, shapes, dev, ctx.expected)
         d_rgb = L.f32c(d_rgb) if d_rgb is not None else torch.zeros(P, 3, device=dev)
         d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, device=dev)
         ws2 = torch.empty(_ceil32(P) * lib.nerf_mlp_ngp_ws2_floats_per_point(), device=dev)
@@ -424,6 +481,9 @@ class _NgpMLP(torch.autograd.Function):
                                      L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(ws2),
                                      L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.ptr(work), nbytes,
                                      L.stream_of(rgb)), "nerf_mlp_ngp_bwd")
+        if sink is not None:
+            sink.done(ctx.params)
+            return (None,) * (5 + len(grads))
         return (None, None, None, None, None, *grads)
 
 

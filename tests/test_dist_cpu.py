@@ -136,3 +136,35 @@ def test_grad_average_and_gather_two_ranks():
         out = mgr.dict()
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def test_gradient_sink_waits_for_every_op_call_of_a_bucket():
+    """The fused ops deliver gradients straight into the bucket views and report through expect()/done().  A model
+    that serves two passes of a render reports twice: its bucket is complete after the second report, not the
+    first; a bucket none of whose parameters was touched is left to finish()."""
+    from nerf_amd.dist import GradBuckets
+    a = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(0, 4))]
+    b = [torch.nn.Parameter(torch.zeros(2, 2))]
+    gb = GradBuckets([a, b])
+    gb.zero_grad()
+    assert [t.data_ptr() for t in gb.targets(a[:2])] == [v.data_ptr() for v in gb.views[0][:2]]
+    assert gb.targets([torch.nn.Parameter(torch.zeros(3))]) is None          # a stranger: the sink declines
+    # an earlier chunk: forward, backward, nothing armed
+    gb.expect(a)
+    gb.done(a)
+    assert gb._sent == [False, False] and gb._pending == [0, 0]
+    # the last chunk: two op calls on the same parameters
+    gb.expect(a)
+    gb.expect(a)
+    gb.arm()
+    gb.done(a)
+    assert gb._sent == [False, False]
+    gb.done(a)
+    assert gb._sent == [True, False]
+    gb.finish()
+    assert gb._sent == [True, True]
+    # the next step starts clean, and a view that is no longer installed as p.grad makes the sink decline
+    gb.zero_grad()
+    assert gb._pending == [0, 0] and gb._sent == [False, False]
+    a[0].grad = torch.zeros(5, 3)
+    assert gb.targets(a[:2]) is None
