@@ -105,11 +105,13 @@ int nerf_hashgrid_fwd(const float* x, int64_t P, const float* const* tables, con
 /* Backward of the above w.r.t. the tables (the reference gets it from the
  * dense nn.Embedding gradient).  d_out [P, 2*levels]; d_tables: host array of
  * device pointers, ACCUMULATED into with float atomics (zero them first).
- * workspace: device scratch of nerf_hashgrid_bwd_workspace_bytes(P, sizes, levels) bytes, with which
- * the updates of the tables too large for LDS are first sorted by table segment and summed in LDS
- * (several times faster at thousands of rays); NULL (or a size of 0, which that function returns
- * for small P) makes every update a float atomic on the table.  Same sums either way, up to the
- * order of the additions. */
+ * workspace: device scratch of nerf_hashgrid_bwd_workspace_bytes(P, sizes, levels) bytes (about
+ * 1.4 KB per point; 16-byte aligned, 128 for whole-line writes), with which the updates of the
+ * tables too large for LDS are first sorted by table segment and summed in LDS (4.5 times faster
+ * at 4 M points); NULL (or a size of 0, which that function returns for small P) makes every
+ * update a float atomic on the table.  Same sums either way, up to the order of the additions and,
+ * for the high-x corner of a corner pair, a few units in the last place (its update is formed
+ * as the low-x corner's times wx / (1 - wx)). */
 size_t nerf_hashgrid_bwd_workspace_bytes(int64_t P, const int* sizes, int levels);
 int nerf_hashgrid_bwd(const float* x, int64_t P, const float* d_out, const int* res,
                       const int* sizes, int levels, float* const* d_tables, void* workspace,
@@ -244,8 +246,9 @@ int nerf_adam_step(int count, float* const* params, const float* const* grads, f
                    float* const* exp_avg_sq, const int64_t* numel, int64_t step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, void* stream);
 /* The same step with the step count in device memory, for a training step that is captured into a
- * HIP graph and replayed (torch.optim.Adam(capturable=True)): a count passed by value would be
- * frozen into the graph.  step_state: 4 device floats, [0] = steps taken so far (0 before the first
+ * HIP graph and replayed: a count passed by value would be frozen into the graph.  No counterpart in
+ * the reference, whose loops step torch.optim.Adam eagerly (torch's own name for this mode is
+ * Adam(capturable=True)).  step_state: 4 device floats, [0] = steps taken so far (0 before the first
  * step; integers are exact in a float up to 2^24 steps).  Every call adds 1 to it (a one-thread
  * launch in front of the update, which also leaves sqrt(1 - beta2^step) in [1] and
  * -lr / (1 - beta1^step) in [2]) and applies the update for that step.  Neither the host nor the
