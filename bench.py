@@ -76,11 +76,6 @@ NGP_WORKLOAD = ("Instant-NGP variant (16 levels, 2^19 rows, 64-wide MLPs), 800x8
                 "%d-ray batch per GPU, one training step incl. Adam over the tables")
 
 
-def ngp_loss(out, gt):
-    """MSE plus the weight regulariser of src/train_nerf_ngp.py:221-222."""
-    return torch.nn.functional.mse_loss(out["rgb"], gt) + 0.05 * (1.0 - out["weights"].sum(dim=-1)).abs().mean()
-
-
 def build_step(kind, rank, rays, dev, chunk_rays, capturable=False):
     """One training step of the vanilla (coarse + fine 8x256 MLPs, 64 + 128 samples) or hash-grid workload:
     fused ray generation + stratified sampling, chunked forward/backward with the gradients in flat buckets
@@ -88,7 +83,7 @@ def build_step(kind, rank, rays, dev, chunk_rays, capturable=False):
     from nerf_amd import ops
     from nerf_amd.dist import GradBuckets
     from nerf_amd.optim import FusedAdam
-    from nerf_amd.render import nerf_loss, train_step
+    from nerf_amd.render import nerf_loss, ngp_loss, train_step   # ngp_loss: MSE + the weight regulariser of src/train_nerf_ngp.py:221-222
 
     c2w, pix, u_c, u_f, gt = make_batch(rank, rays, dev)
     if kind == "ngp":

@@ -139,6 +139,22 @@ int nerf_composite_bwd(const float* rgb, const float* sigma, const float* z, con
                        const float* d_weights, const float* d_depth, int64_t R, int N,
                        int white_bkgd, float tail_dist, float* d_rgb, float* d_sigma, void* stream);
 
+/* The training loss of the reference's loops and its gradient, one pass each:
+ *   loss = mean((rgb - target)^2) [+ mean((rgb_fine - target)^2)] [+ reg * mean_r |1 - sum_n weights[r][n]|]
+ * -- the MSE of the rendered colours (src/train_nerf_llff.py:116, src/train_nerf_skow.py:168), of both passes
+ * of a hierarchical render when rgb_fine is given, plus the weight regulariser of the hash-grid loop
+ * (src/train_nerf_ngp.py:221-222: reg = 0.05) when weights [R,N] is given.  rgb, rgb_fine, target [R,3].
+ * workspace: nerf_render_loss_workspace_floats(R) floats; loss: one device float.  The sums are formed in a
+ * fixed order.  bwd: d_loss = one device float (the gradient of the loss itself); d_rgb, d_rgb_fine [R,3],
+ * d_weights [R,N] are WRITTEN (any of them may be NULL). */
+size_t nerf_render_loss_workspace_floats(int64_t R);
+int nerf_render_loss_fwd(const float* rgb, const float* rgb_fine, const float* target,
+                         const float* weights, int64_t R, int N, float reg, float* workspace,
+                         float* loss, void* stream);
+int nerf_render_loss_bwd(const float* rgb, const float* rgb_fine, const float* target,
+                         const float* weights, int64_t R, int N, float reg, const float* d_loss,
+                         float* d_rgb, float* d_rgb_fine, float* d_weights, void* stream);
+
 /* Occupancy-grid masking of per-sample densities, the step between the model and the compositor in
  * render_image (src/train_nerf_ngp.py:113-117) and render_from_model
  * (src/utils/analyze_capture_results.py:283-287): out[p] = values[p] where grid[cell(p)] == 1, else 0, with

@@ -256,6 +256,116 @@ __global__ __launch_bounds__(256) void occupancy_mask_kernel(const float* __rest
     out[p] = grid[idx] == 1 ? in[p] : 0.0f;
 }
 
+
+// ---------------------------------------------------------------------------
+// The training loss of the reference's loops and its gradient, one pass each:
+//   loss = mean((rgb - target)^2) [+ mean((rgb_fine - target)^2)] [+ reg * mean_r |1 - sum_n weights[r][n]|]
+// (MSE of the rendered colours, src/train_nerf_llff.py:116; plus the weight regulariser of the hash-grid loop,
+// src/train_nerf_ngp.py:221-222).  As separate tensor ops this is some twenty launches of a few microseconds each,
+// forward and backward, a tenth of a 4096-ray hash-grid step.  The sums are formed in a fixed order (per thread,
+// per wave, per workgroup, then one workgroup over the partials): the same bits from run to run.
+// ---------------------------------------------------------------------------
+constexpr int LOSS_THREADS = 256, LOSS_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(LOSS_THREADS) void render_loss_partial_kernel(const float* __restrict__ rgb,
+                                                                           const float* __restrict__ rgb_fine,
+                                                                           const float* __restrict__ target,
+                                                                           const float* __restrict__ weights, int64_t R, int N,
+                                                                           float* __restrict__ partials) {
+    __shared__ float s_part[3][LOSS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float se = 0.0f, sf = 0.0f, sr = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * LOSS_THREADS + tid; i < 3 * R; i += (int64_t)gridDim.x * LOSS_THREADS) {
+        const float t = target[i], e = rgb[i] - t;
+        se += e * e;
+        if (rgb_fine) {
+            const float f = rgb_fine[i] - t;
+            sf += f * f;
+        }
+    }
+    if (weights) {   // one wavefront per ray: its N weights are contiguous
+        const int64_t wave_id = (int64_t)blockIdx.x * (LOSS_THREADS / 64) + wave, waves = (int64_t)gridDim.x * (LOSS_THREADS / 64);
+        for (int64_t r = wave_id; r < R; r += waves) {
+            float s = 0.0f;
+            for (int n = lane; n < N; n += 64) s += weights[r * N + n];
+            s = wave_sum(s);
+            if (lane == 0) sr += fabsf(1.0f - s);
+        }
+    }
+    se = wave_sum(se);
+    sf = wave_sum(sf);
+    sr = wave_sum(sr);
+    if (lane == 0) {
+        s_part[0][wave] = se;
+        s_part[1][wave] = sf;
+        s_part[2][wave] = sr;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        float s = 0.0f;
+#pragma unroll
+        for (int v = 0; v < LOSS_THREADS / 64; ++v) s += s_part[tid][v];
+        partials[3 * blockIdx.x + tid] = s;
+    }
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void render_loss_final_kernel(const float* __restrict__ partials, int blocks, int64_t R,
+                                                                         float reg, float* __restrict__ loss) {
+    __shared__ double s_sum[3][LOSS_THREADS];
+    const int tid = threadIdx.x;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = tid; b < blocks; b += LOSS_THREADS)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += (double)partials[3 * b + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_sum[k][tid] = s[k];
+    __syncthreads();
+    for (int d = LOSS_THREADS / 2; d > 0; d >>= 1) {
+        if (tid < d)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_sum[k][tid] += s_sum[k][tid + d];
+        __syncthreads();
+    }
+    if (tid == 0)
+        *loss = (float)(s_sum[0][0] / (double)(3 * R)) + (float)(s_sum[1][0] / (double)(3 * R)) +
+                reg * (float)(s_sum[2][0] / (double)R);
+}
+
+// d_rgb = g * 2 (rgb - target) / (3 R), the same for the fine colours, d_weights[r][n] = -g * reg * sign(1 - sum_n
+// weights[r][.]) / R; g = the gradient of the loss itself, read from memory.
+__global__ __launch_bounds__(LOSS_THREADS) void render_loss_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb_fine,
+                                                                       const float* __restrict__ target,
+                                                                       const float* __restrict__ weights, int64_t R, int N,
+                                                                       float reg, const float* __restrict__ d_loss,
+                                                                       float* __restrict__ d_rgb, float* __restrict__ d_rgb_fine,
+                                                                       float* __restrict__ d_weights) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float g = *d_loss;
+    const float c = g * (2.0f / (float)(3 * R));
+    for (int64_t i = (int64_t)blockIdx.x * LOSS_THREADS + tid; i < 3 * R; i += (int64_t)gridDim.x * LOSS_THREADS) {
+        const float t = target[i];
+        if (d_rgb) d_rgb[i] = c * (rgb[i] - t);
+        if (d_rgb_fine) d_rgb_fine[i] = c * (rgb_fine[i] - t);
+    }
+    if (d_weights) {
+        const float cw = -(g * reg) / (float)R;
+        const int64_t wave_id = (int64_t)blockIdx.x * (LOSS_THREADS / 64) + wave, waves = (int64_t)gridDim.x * (LOSS_THREADS / 64);
+        for (int64_t r = wave_id; r < R; r += waves) {
+            float s = 0.0f;
+            for (int n = lane; n < N; n += 64) s += weights[r * N + n];
+            s = wave_sum(s);
+            const float d = 1.0f - s;
+            const float v = d > 0.0f ? cw : d < 0.0f ? -cw : 0.0f;   // sign(0) = 0, as torch's abs backward
+            for (int n = lane; n < N; n += 64) d_weights[r * N + n] = v;
+        }
+    }
+}
+
+static int loss_blocks(int64_t R) {
+    const int64_t b = ceil_div(R, 64);   // at least 64 rays per workgroup
+    return (int)(b < 1 ? 1 : b > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : b);
+}
+
 }  // namespace nerf
 
 using namespace nerf;
@@ -307,4 +417,30 @@ extern "C" int nerf_occupancy_mask(const float* pts, const float* values, int64_
     hipLaunchKernelGGL(occupancy_mask_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, pts,
                        values, P, grid, grid_cells, cell, out);
     return check_launch("nerf_occupancy_mask");
+}
+
+extern "C" size_t nerf_render_loss_workspace_floats(int64_t R) { return R > 0 ? 3 * (size_t)loss_blocks(R) : 0; }
+
+extern "C" int nerf_render_loss_fwd(const float* rgb, const float* rgb_fine, const float* target, const float* weights,
+                                    int64_t R, int N, float reg, float* workspace, float* loss, void* stream) {
+    NERF_REQUIRE(rgb && target && workspace && loss, "nerf_render_loss_fwd: null pointer");
+    NERF_REQUIRE(R > 0 && (!weights || N > 0), "nerf_render_loss_fwd: R=%lld N=%d", (long long)R, N);
+    const int blocks = loss_blocks(R);
+    hipLaunchKernelGGL(render_loss_partial_kernel, dim3(blocks), dim3(LOSS_THREADS), 0, (hipStream_t)stream, rgb, rgb_fine, target,
+                       weights, R, N, workspace);
+    if (int rc = check_launch("nerf_render_loss_fwd")) return rc;
+    hipLaunchKernelGGL(render_loss_final_kernel, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, workspace, blocks, R,
+                       weights ? reg : 0.0f, loss);
+    return check_launch("nerf_render_loss_fwd(final)");
+}
+
+extern "C" int nerf_render_loss_bwd(const float* rgb, const float* rgb_fine, const float* target, const float* weights,
+                                    int64_t R, int N, float reg, const float* d_loss, float* d_rgb, float* d_rgb_fine,
+                                    float* d_weights, void* stream) {
+    NERF_REQUIRE(rgb && target && d_loss, "nerf_render_loss_bwd: null pointer");
+    NERF_REQUIRE(R > 0 && (!d_weights || (weights && N > 0)) && (!d_rgb_fine || rgb_fine), "nerf_render_loss_bwd: R=%lld N=%d",
+                 (long long)R, N);
+    hipLaunchKernelGGL(render_loss_bwd_kernel, dim3(loss_blocks(R)), dim3(LOSS_THREADS), 0, (hipStream_t)stream, rgb, rgb_fine,
+                       target, weights, R, N, reg, d_loss, d_rgb, d_rgb_fine, d_weights);
+    return check_launch("nerf_render_loss_bwd");
 }

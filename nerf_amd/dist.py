@@ -212,7 +212,9 @@ def accumulate_step(n_items: int, chunk: int, loss_of_chunk: Callable[[int, int]
     spans = [(lo, min(lo + chunk, n_items)) for lo in range(0, n_items, chunk)]
     with sink:
         for k, (lo, hi) in enumerate(spans):
-            loss = loss_of_chunk(lo, hi) * ((hi - lo) / n_items)
+            loss = loss_of_chunk(lo, hi)
+            if hi - lo != n_items:
+                loss = loss * ((hi - lo) / n_items)
             if buckets is not None and k == len(spans) - 1:
                 buckets.arm()
             (loss * grad_scale if grad_scale != 1.0 else loss).backward()

@@ -265,6 +265,53 @@ def occupancy_mask(sigma, pts, grid, grid_res: int):
     return _OccupancyMask.apply(sigma, pts, grid, int(grid_res))
 
 
+class _RenderLoss(torch.autograd.Function):
+    """loss = mse(rgb, target) [+ mse(rgb_fine, target)] [+ reg * mean |1 - weights.sum(-1)|] in two launches,
+    its gradient in one (src/train_nerf_llff.py:116, src/train_nerf_ngp.py:221-222)."""
+
+    @staticmethod
+    def forward(ctx, rgb, target, rgb_fine, weights, reg):
+        L.need_gpu(rgb, target)
+        lib = L.lib()
+        c, t = L.f32c(rgb.detach()), L.f32c(target.detach())
+        f = L.f32c(rgb_fine.detach()) if rgb_fine is not None else None
+        w = L.f32c(weights.detach()) if weights is not None else None
+        R = c.shape[0]
+        assert c.shape == (R, 3) and t.shape == (R, 3) and R > 0, "rgb and target must be [R,3]"
+        assert f is None or f.shape == (R, 3), "rgb_fine must be [R,3]"
+        assert w is None or (w.dim() == 2 and w.shape[0] == R), "weights must be [R,N]"
+        N = int(w.shape[1]) if w is not None else 0
+        work = torch.empty(lib.nerf_render_loss_workspace_floats(R), device=c.device)
+        loss = torch.empty((), device=c.device)
+        L.check(lib.nerf_render_loss_fwd(L.ptr(c), L.ptr(f), L.ptr(t), L.ptr(w), R, N, float(reg), L.ptr(work), L.ptr(loss),
+                                         L.stream_of(c)), "nerf_render_loss_fwd")
+        ctx.save_for_backward(c, t, f, w)
+        ctx.meta = (R, N, float(reg), rgb.shape, None if rgb_fine is None else rgb_fine.shape,
+                    None if weights is None else weights.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        c, t, f, w = ctx.saved_tensors
+        R, N, reg, s_rgb, s_fine, s_w = ctx.meta
+        need_c, _, need_f, need_w, _ = ctx.needs_input_grad
+        g = L.f32c(d_loss).reshape(1)
+        d_c = torch.empty_like(c) if need_c else None
+        d_f = torch.empty_like(f) if (need_f and f is not None) else None
+        d_w = torch.empty_like(w) if (need_w and w is not None) else None
+        L.check(L.lib().nerf_render_loss_bwd(L.ptr(c), L.ptr(f), L.ptr(t), L.ptr(w), R, N, reg, L.ptr(g), L.ptr(d_c), L.ptr(d_f),
+                                             L.ptr(d_w), L.stream_of(c)), "nerf_render_loss_bwd")
+        return (None if d_c is None else d_c.view(s_rgb), None, None if d_f is None else d_f.view(s_fine),
+                None if d_w is None else d_w.view(s_w), None)
+
+
+def render_loss(rgb, target, rgb_fine=None, weights=None, reg: float = 0.0) -> torch.Tensor:
+    """The training loss of the reference's loops as one fused op: ``mse_loss(rgb, target)`` (src/train_nerf_llff.py:116),
+    plus ``mse_loss(rgb_fine, target)`` for a hierarchical render, plus ``reg * (1 - weights.sum(-1)).abs().mean()``
+    (the hash-grid loop's regulariser, src/train_nerf_ngp.py:221-222, reg = 0.05).  The target receives no gradient."""
+    return _RenderLoss.apply(rgb, target, rgb_fine, weights if reg != 0.0 else None, float(reg))
+
+
 # ---------------------------------------------------------- fused MLPs ----
 def _ceil32(n: int) -> int:
     return (n + 31) // 32 * 32

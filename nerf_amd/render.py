@@ -244,8 +244,18 @@ def psnr(x, y):
 
 def nerf_loss(out: dict, target: torch.Tensor) -> torch.Tensor:
     """MSE of the coarse colour (src/train_nerf_llff.py:116) plus, when a fine
-    pass was rendered, the MSE of the fine colour."""
+    pass was rendered, the MSE of the fine colour.  On the GPU one fused op (``ops.render_loss``)."""
+    if out["rgb"].is_cuda and out["rgb"].dtype == torch.float32 and out["rgb"].dim() == 2 and out["rgb"].shape[0] > 0:
+        return ops.render_loss(out["rgb"], target, out.get("rgb_fine"))
     loss = torch.nn.functional.mse_loss(out["rgb"], target)
     if "rgb_fine" in out:
         loss = loss + torch.nn.functional.mse_loss(out["rgb_fine"], target)
     return loss
+
+
+def ngp_loss(out: dict, target: torch.Tensor, reg: float = 0.05) -> torch.Tensor:
+    """The hash-grid loop's loss (src/train_nerf_ngp.py:221-222): MSE plus ``reg`` times the mean deviation of
+    the rays' summed compositing weights from 1.  On the GPU one fused op (``ops.render_loss``)."""
+    if out["rgb"].is_cuda and out["rgb"].dtype == torch.float32 and out["rgb"].dim() == 2 and out["rgb"].shape[0] > 0:
+        return ops.render_loss(out["rgb"], target, weights=out["weights"], reg=reg)
+    return torch.nn.functional.mse_loss(out["rgb"], target) + reg * (1.0 - out["weights"].sum(dim=-1)).abs().mean()

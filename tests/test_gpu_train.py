@@ -495,3 +495,35 @@ def test_psnr_after_320_steps_matches_the_reference_trajectory(dev):
     for a, b in zip(psnrs, want_psnr):
         assert abs(a - float(b)) < 0.25, (psnrs, want_psnr)
     assert losses[-1] < 0.5 * losses[0]                     # it trained
+
+
+def test_fused_render_loss_matches_the_tensor_ops(dev):
+    """ops.render_loss (MSE of one or two colour maps + the hash-grid loop's weight regulariser, value and gradient)
+    against the same loss written with torch's ops, at ragged sizes and with a scaled upstream gradient."""
+    from nerf_amd import ops
+    gen = torch.Generator().manual_seed(31)
+    for R, N in [(1, 2), (77, 17), (4096, 64), (5000, 192)]:
+        base = [torch.rand(R, 3, generator=gen), torch.rand(R, 3, generator=gen), torch.rand(R, 3, generator=gen),
+                torch.rand(R, N, generator=gen) * (2.2 / N)]
+        base[3][0] = 1.0 / N                                   # a ray whose weights sum to 1 (to rounding)
+        for with_fine, reg in [(False, 0.0), (True, 0.0), (False, 0.05), (True, 0.3)]:
+            rgb, fine, tgt, w = (t.clone().to(dev) for t in base)
+            a = [t.clone().requires_grad_(True) for t in (rgb, fine, w)]
+            b = [t.clone().requires_grad_(True) for t in (rgb, fine, w)]
+            want = torch.nn.functional.mse_loss(a[0], tgt)
+            if with_fine:
+                want = want + torch.nn.functional.mse_loss(a[1], tgt)
+            if reg:
+                want = want + reg * (1.0 - a[2].sum(dim=-1)).abs().mean()
+            got = ops.render_loss(b[0], tgt, b[1] if with_fine else None, b[2] if reg else None, reg)
+            assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want)), (R, N, with_fine, reg)
+            (want * 0.37).backward()
+            (got * 0.37).backward()
+            for x, y in zip(a, b):
+                if x.grad is None:
+                    assert y.grad is None
+                    continue
+                scale = float(x.grad.abs().max())
+                # the regulariser's gradient is a sign: rays whose weights sum to 1 within rounding may take either
+                bad = (x.grad - y.grad).abs() > 2e-6 * scale + 1e-12
+                assert int(bad.sum()) <= (N if reg else 0), (R, N, with_fine, reg, int(bad.sum()))
