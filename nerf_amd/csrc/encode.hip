@@ -165,9 +165,15 @@ __global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const 
     __syncthreads();
     const int64_t per = (P + gridDim.x - 1) / gridDim.x;
     const int64_t p_begin = per * blockIdx.x, p_end = min(P, p_begin + per);
-    for (int64_t t = 4 * p_begin + tid; t < 4 * p_end; t += HG_LDS_THREADS) {
-        const int64_t p = t >> 2;
-        const int f = (int)t & 1, cx = ((int)t >> 1) & 1;
+    // 256 points per round, four threads each.  Consecutive points are consecutive samples of a ray and share a
+    // cell at these resolutions: taken in order, the 16 points of a wave instruction would add to the same rows
+    // (same-address LDS atomics run one lane after the other).  Within a round the points are taken in the order of
+    // a transposed 16 x 16 block, so that a wave holds points 16 apart.
+    for (int64_t t0 = p_begin; t0 < p_end; t0 += HG_LDS_THREADS / 4) {
+        const int li = tid >> 2;
+        const int64_t p = t0 + ((li & 15) * 16 + (li >> 4));
+        if (p >= p_end) continue;
+        const int f = tid & 1, cx = (tid >> 1) & 1;
         const Cell c = locate(x, p, res);
         const float g = d_out[denc_index(p, l, levels, level_stride) + f];
         const unsigned px = cx ? c.hi[0] : c.lo[0];
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const 
 // do not sit in the row after their partner (x wrap, segment boundary) go to the table directly.
 // ---------------------------------------------------------------------------
 constexpr int BIN_SEG_ROWS = 8192;    // 128 KiB of double2
-constexpr int BIN_PTS = 512;
+constexpr int BIN_PTS = 512;          // 8 waves (the point-to-thread mapping of the bin kernel is written for that)
 constexpr int BIN_REC = 4 * BIN_PTS;
 constexpr int BIN_MAX_SEGS = 64;
 constexpr int BIN_RUN = 8;            // records per 128-byte line
@@ -265,20 +271,34 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
     __shared__ unsigned s_dest[BIN_SLOTS];
     __shared__ float4 s_rec[BIN_SLOTS];
     const int tid = threadIdx.x;
-    const int64_t p = (int64_t)blockIdx.x * BIN_PTS + tid;
+    // Which of the workgroup's 512 points a thread takes: consecutive points are consecutive samples of a ray and,
+    // on the coarser levels, fall into the same cell -- their records would sit side by side in a queue and the
+    // reduce pass would add them to the same row in one instruction, the slowest case of an LDS atomic.  Wave w
+    // takes the points w, w + 8, w + 16, ... of each of eight runs of 64: neighbours end up in different waves,
+    // whose records enter the queues at different times.
+    // Loads stay coalesced: thread t loads point t and hands it to its owner through the record buffer, which is idle
+    // at that point of the loop.
+    const int pt_in_wg = ((tid & 63) >> 3) * 64 + (tid >> 6) + 8 * (tid & 7);
+    const int64_t p = (int64_t)blockIdx.x * BIN_PTS + pt_in_wg;
     const bool valid = p < P;
-    const int64_t pl = valid ? p : P - 1;
-    const float xyz[3] = {x[3 * pl], x[3 * pl + 1], x[3 * pl + 2]};
-    float2 g_next = *reinterpret_cast<const float2*>(d_out + denc_index(pl, lv.id[0], levels, level_stride));
+    const int64_t p_load = min((int64_t)blockIdx.x * BIN_PTS + tid, P - 1);   // the point this thread loads
+    float* s_xch = reinterpret_cast<float*>(s_rec);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s_xch[3 * tid + k] = x[3 * p_load + k];
+    float2 g_next = *reinterpret_cast<const float2*>(d_out + denc_index(p_load, lv.id[0], levels, level_stride));
+    __syncthreads();
+    const float xyz[3] = {s_xch[3 * pt_in_wg], s_xch[3 * pt_in_wg + 1], s_xch[3 * pt_in_wg + 2]};
+    __syncthreads();
 #pragma unroll 1
     for (int j = 0; j < lv.n; ++j) {
         const unsigned size = lv.size[j], cap = lv.cap[j];
         const int nseg = lv.nseg[j], nsub = lv.nsub[j], sub = blockIdx.x % nsub;
-        const float2 g = g_next;   // requested an iteration ago
-        if (j + 1 < lv.n) g_next = *reinterpret_cast<const float2*>(d_out + denc_index(pl, lv.id[j + 1], levels, level_stride));
         float* __restrict__ tab = lv.table[j];
+        reinterpret_cast<float2*>(s_xch)[tid] = g_next;   // requested an iteration ago
+        if (j + 1 < lv.n) g_next = *reinterpret_cast<const float2*>(d_out + denc_index(p_load, lv.id[j + 1], levels, level_stride));
         if (tid < BIN_MAX_SEGS) s_hist[tid] = 0u;
         __syncthreads();
+        const float2 g = reinterpret_cast<const float2*>(s_xch)[pt_in_wg];
         const Cell c = locate3(xyz, lv.res[j]);
         const float rho = c.w[0] / (1.0f - c.w[0]);   // w is a fractional part: 1 - w > 0
         unsigned seg[4], pos[4], loc[4];
