@@ -580,7 +580,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
             else wgrad_part_pk<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds);
             break;
         case 1: wgrad_part_pk<1, 8, 1, 3>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        case 2: wgrad_part_pk<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        default: wgrad_part_pk<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;   // 2; the narrow shapes 3-5: wgrad_small_kernel
+    }
+}
+
+// The narrow shapes of the hash-grid model in a kernel of their own: their two chunk buffers take 32 KiB and their
+// accumulators a few dozen registers, so several workgroups fit a CU -- in wgrad_kernel they inherited its 148 KiB of
+// LDS and 480 registers, i.e. four waves per CU for work that is bound by its reads (1.59 ms for 7 GB).
+constexpr int WG_SMALL_LDS_FLOATS = 2 * WG_CH * (64 + 32 + 32);
+static_assert(2 * WgradShape<1, 1, 0, 2>::CHUNK <= WG_SMALL_LDS_FLOATS && 2 * WgradShape<1, 2, 0, 1>::CHUNK <= WG_SMALL_LDS_FLOATS &&
+                  2 * WgradShape<1, 1, 1, 2>::CHUNK <= WG_SMALL_LDS_FLOATS, "chunk buffers of the narrow shapes");
+__global__ __launch_bounds__(256) void wgrad_small_kernel(WgradParts parts) {
+    __shared__ __attribute__((aligned(16))) float lds[WG_SMALL_LDS_FLOATS];
+    int pi = 0;
+#pragma unroll 1
+    while (pi + 1 < parts.n && (int)blockIdx.x >= parts.part[pi + 1].first_block) ++pi;
+    const WgradPart& pt = parts.part[pi];
+    const int slab = blockIdx.x - pt.first_block;
+    const long long tiles = parts.P32 / 32;
+    const long long t0 = tiles * slab / pt.slabs, t1 = tiles * (slab + 1) / pt.slabs;
+    if (t0 >= t1) return;   // uniform for the whole workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    switch (pt.shape) {
         case 3: wgrad_part<1, 1, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 4: wgrad_part<1, 2, 0, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         default: wgrad_part<1, 1, 1, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
@@ -593,12 +614,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
 static const int kShapeCost[6] = {24, 19, 17, 8, 8, 8};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
-    // A workgroup takes a whole CU (512 registers per lane), so the grid is sized
-    // to exactly two equal-cost rounds of the 256 CUs: slabs proportional to cost.
+    // A list is either the wide split-f16 shapes (a workgroup takes a whole CU: 512 registers per lane, so the grid is
+    // sized to exactly two equal-cost rounds of the 256 CUs, slabs proportional to cost) or the narrow shapes of the
+    // hash-grid model (several workgroups per CU: four rounds' worth of smaller slabs).
+    bool narrow = parts.n > 0 && parts.part[0].shape >= 3;
+    for (int i = 0; i < parts.n; ++i)
+        if ((parts.part[i].shape >= 3) != narrow) return fail(NERF_EINVAL, "wgrad: wide and narrow shapes in one list");
     long long total_cost = 0;
     for (int i = 0; i < parts.n; ++i) total_cost += kShapeCost[parts.part[i].shape];
     const long long tiles = P32 / 32;
-    const int target_blocks = 512;
+    // narrow: at least 64 tiles (2048 points) per slab -- every workgroup ends in atomics on the same few lines of
+    // the gradients -- and at most 2048 workgroups
+    const long long narrow_blocks = parts.n * tiles / 64;
+    const int target_blocks = !narrow ? 512 : (int)(narrow_blocks < 256 ? 256 : narrow_blocks > 2048 ? 2048 : narrow_blocks);
     int used = 0;
     for (int i = 0; i < parts.n; ++i) {
         long long s = target_blocks * (long long)kShapeCost[parts.part[i].shape] / total_cost;
@@ -626,7 +654,8 @@ int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     }
     parts.total_blocks = first;
     parts.P32 = P32;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(first), dim3(256), 0, stream, parts);
+    if (narrow) hipLaunchKernelGGL(wgrad_small_kernel, dim3(first), dim3(256), 0, stream, parts);
+    else hipLaunchKernelGGL(wgrad_kernel, dim3(first), dim3(256), 0, stream, parts);
     return check_launch("wgrad");
 }
 
