@@ -91,7 +91,7 @@ __device__ __forceinline__ void store16(float* __restrict__ dst, const f32x16& v
 }
 
 template <bool SAVE>
-__global__ __launch_bounds__(256, 4) void ngp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
+__global__ __launch_bounds__(256, 3) void ngp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                       int dirs_div, long long P,
                                                       const float* __restrict__ pk, float* __restrict__ rgb,
                                                       float* __restrict__ sigma, float* __restrict__ ws) {
