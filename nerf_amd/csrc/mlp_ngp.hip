@@ -112,7 +112,24 @@ __global__ __launch_bounds__(256, 3) void ngp_fwd_kernel(const float* __restrict
         e[0][2 * j] = v.x;
         e[0][2 * j + 1] = v.y;
     }
-    if (SAVE) store16(ws + ix.P32 * nw::E + ix.gp * 32 + 16 * h, e[0]);
+    if (SAVE) {
+        // the saved encoding leaves as whole rows too: lane (p, h) holds features 16h .. 16h+15 of point p, which go into
+        // row p of the wave's transposition buffer, and the buffer goes out 128 contiguous bytes per 8 lanes
+        const unsigned wr_e = lds_addr(s_tile[threadIdx.x >> 6] + (lane & 31) * TILE_LD + 16 * h);
+        static_for<0, 4>([&](auto cq) {
+            constexpr int q = decltype(cq)::value;
+            lds_write4<16 * q>(wr_e, f32x4{e[0][4 * q], e[0][4 * q + 1], e[0][4 * q + 2], e[0][4 * q + 3]});
+        });
+        f32x4 v[4];
+        static_for<0, 4>([&](auto ck) { v[ck] = lds_read4<8 * decltype(ck)::value * TILE_LD * 4>(tb.rd); });
+        lgkm_wait();
+        float* rows0 = ws + ix.P32 * nw::E + ix.tile * (32 * 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            asm volatile("" : "+v"(v[k]));
+            __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(rows0 + (size_t)(8 * k + tb.row) * 32 + tb.col));
+        }
+    }
     // ---- density MLP: raw = W2 relu(W1 e + b1) + b2        (FastNGPNeRF.py:90)
     f32x16 hd[2];
     fill_rows<2>(hd, pk + np::S_BD1, h);
