@@ -22,3 +22,8 @@ python3 tools/summarize_pmc.py "$OUT"/mfma/*/*_counter_collection.csv "$OUT"/fet
 python3 tools/summarize_pmc.py "$OUT"/kfetch/*/*_counter_collection.csv "$OUT"/kwrite/*/*_counter_collection.csv > "$OUT/bench_kernels_pmc_summary.txt"
 ls "$OUT"
 python3 tools/make_traffic_json.py "$OUT" > "$OUT/roofline_traffic.json"
+# the hash-grid step by itself at the data-parallel and at the single-GPU batch, and the launch-by-launch timeline of the latter
+bash tools/trace_ngp.sh 65536 "$OUT/ngp_65536" > /dev/null
+bash tools/trace_ngp.sh 4096 "$OUT/ngp_4096" > /dev/null
+cp "$OUT/ngp_65536/kernels_by_grid.txt" "$OUT/ngp_65536rays_kernels_by_grid.txt"
+python3 tools/step_timeline.py "$(ls "$OUT"/ngp_4096/trace/*/*_kernel_trace.csv | head -1)" > "$OUT/ngp_4096rays_step_timeline.txt"
