@@ -726,7 +726,7 @@ int launch_skinny(const SkinnyPart& pt, long long P32, hipStream_t stream) {
     NERF_REQUIRE(pt.ldY == 4 && pt.C >= 1 && pt.c0 + pt.C <= 4, "skinny_wgrad: dY must be rows of 4 floats");
     NERF_REQUIRE(pt.ldX % 4 == 0 && ((size_t)pt.X % 16) == 0 && ((size_t)pt.dY % 16) == 0, "skinny_wgrad: rows must be 16-byte aligned");
     const long long want = P32 / 256;   // at least 256 points per workgroup
-    const int blocks = (int)(want < 1 ? 1 : want > 256 ? 256 : want);
+    const int blocks = (int)(want < 1 ? 1 : want > 512 ? 512 : want);   // two workgroups per CU at most (64 KiB of LDS each)
     const dim3 block(SKINNY_THREADS);
     switch (pt.K) {
         case 256: hipLaunchKernelGGL(skinny_wgrad_kernel<256>, dim3(blocks), block, 0, stream, pt, P32); break;
