@@ -132,7 +132,10 @@ def build_ngp_step(rank, rays, dev, chunk_rays, world, use_graph):
             eager, model = build_step("ngp", rank, rays, dev, chunk_rays, capturable=True)
             return GraphedStep(eager, warmup=3), model, {"hip_graph": True}
         except Exception as e:   # the same kernels run eagerly; the line says so
-            torch.cuda.synchronize()
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
             step, model = build_step("ngp", rank, rays, dev, chunk_rays)
             return step, model, {"hip_graph": False, "hip_graph_error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     step, model = build_step("ngp", rank, rays, dev, chunk_rays)
