@@ -47,7 +47,7 @@ SIGNATURES = {
     "nerf_mlp_ngp_ws2_floats_per_point": (C.c_size_t, []),
     "nerf_mlp_ngp_pack": (_I, [_P, _P, _P]),
     "nerf_mlp_ngp_fwd": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "nerf_mlp_ngp_bwd": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "nerf_mlp_ngp_bwd": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I, _P]),
     "nerf_render_loss_workspace_floats": (C.c_size_t, [_L]),
     "nerf_render_loss_fwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "nerf_render_loss_bwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),

@@ -321,19 +321,24 @@ extern "C" int nerf_mlp_ngp_fwd(const float* x, const float* dirs, int dirs_div,
 extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, int64_t P, const int* res,
                                 const int* sizes, const float* packed, const float* rgb, const float* sigma, float* ws,
                                 float* ws2, float* const* d_tables, float* const* grads, void* scatter_ws,
-                                size_t scatter_ws_bytes, void* stream) {
+                                size_t scatter_ws_bytes, int phases, void* stream) {
     if (P == 0) return NERF_OK;
     NERF_REQUIRE(x && d_rgb && d_sigma && res && sizes && packed && rgb && sigma && ws && ws2 && d_tables && grads,
                  "nerf_mlp_ngp_bwd: null pointer");
+    NERF_REQUIRE(phases >= 1 && phases <= 3, "nerf_mlp_ngp_bwd: phases=%d", phases);
     for (int i = 0; i < NERF_NGP_NPARAM; ++i) NERF_REQUIRE(grads[i], "nerf_mlp_ngp_bwd: gradient %d is null", i);
     if (int rc = check_levels(res, sizes, "nerf_mlp_ngp_bwd")) return rc;
     for (int l = 0; l < 16; ++l) NERF_REQUIRE(d_tables[l], "nerf_mlp_ngp_bwd: gradient table %d is null", l);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ngp_bwd_data_kernel, dim3((unsigned)ceil_div(P, 128)), dim3(256), 0, st, x, d_rgb, d_sigma,
-                       (long long)P, packed, rgb, sigma, ws, ws2);
-    if (int rc = check_launch("nerf_mlp_ngp_bwd(data)")) return rc;
-
     const long long P32 = (P + 31) / 32 * 32;
+    if (phases & 1) {   // the backward-data chain and the table gradients, which are complete when these launches are
+        hipLaunchKernelGGL(ngp_bwd_data_kernel, dim3((unsigned)ceil_div(P, 128)), dim3(256), 0, st, x, d_rgb, d_sigma,
+                           (long long)P, packed, rgb, sigma, ws, ws2);
+        if (int rc = check_launch("nerf_mlp_ngp_bwd(data)")) return rc;
+        if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, P32, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st)) return rc;
+    }
+    if (!(phases & 2)) return NERF_OK;
+
     const float *E = ws + P32 * nw::E, *HD = ws + P32 * nw::HD, *RAW = ws + P32 * nw::RAW, *DE = ws + P32 * nw::DE,
                 *HC = ws + P32 * nw::HC;
     const float *DYC = ws2 + P32 * nw::DYC, *DRAW = ws2 + P32 * nw::DRAW, *DYD = ws2 + P32 * nw::DYD,
@@ -356,7 +361,6 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
         p.k_first = 1;
         parts.part[n++] = p;
     }
-    if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, P32, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st)) return rc;
     parts.n = n;
     if (int rc = launch_wgrad(parts, P32, st)) return rc;
     SkinnyPart c2{DOUT4, HC, grads[6], grads[7], 4, 64, 1, 3, 64};                                           // fc_color.2

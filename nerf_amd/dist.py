@@ -79,7 +79,7 @@ class GradBuckets:
             self.views.append(views)
         self._armed = False
         self._got: List[set] = [set() for _ in self.buckets]   # parameters of the bucket whose gradient is complete
-        self._pending = [0] * len(self.buckets)                # fused-op calls forwarded whose backward is still to come
+        self._pending = [0] * len(self.buckets)                # gradient deliveries announced by fused ops (expect) and not yet made (done)
         self._work: List[Optional[object]] = [None] * len(self.buckets)
         self._sent = [False] * len(self.buckets)
         # parameter storage -> (bucket, index in bucket, view): the gradient sink of the fused ops (below)
@@ -100,26 +100,26 @@ class GradBuckets:
             out.append(slot[2])
         return out
 
-    def _buckets_of(self, params) -> set:
-        return {self._slot[p.data_ptr()][0] for p in params if p.numel() and p.data_ptr() in self._slot}
+    def _slots_of(self, params):
+        return [self._slot[p.data_ptr()] for p in params if p.numel() and p.data_ptr() in self._slot]
 
     def expect(self, params) -> None:
-        """A fused op has run forward on ``params`` and will deliver their gradients through ``done``: a bucket is
-        not complete before every such call has (one model may serve two passes of a render)."""
-        for bi in self._buckets_of(params):
+        """A fused op has run forward on ``params`` and will deliver their gradients through ``done`` (possibly in
+        several parts): a bucket is not complete before every delivery announced for it has arrived (one model may
+        serve two passes of a render)."""
+        for bi, _, _ in self._slots_of(params):
             self._pending[bi] += 1
 
     def done(self, params) -> None:
         """The kernels that accumulate into the views of ``params`` are enqueued -- what the post-accumulate hooks
         report when autograd does the accumulation."""
-        touched = self._buckets_of(params)
-        for bi in touched:
+        touched = set()
+        for bi, pi, _ in self._slots_of(params):
             self._pending[bi] = max(0, self._pending[bi] - 1)
+            touched.add(bi)
+            if self._armed:
+                self._got[bi].add(pi)
         if self._armed:
-            for p in params:
-                slot = self._slot.get(p.data_ptr()) if p.numel() else None
-                if slot is not None:
-                    self._got[slot[0]].add(slot[1])
             for bi in touched:
                 self._maybe_send(bi)
 

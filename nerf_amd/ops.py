@@ -524,13 +524,22 @@ class _NgpMLP(torch.autograd.Function):
         d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, device=dev)
         ws2 = torch.empty(_ceil32(P) * lib.nerf_mlp_ngp_ws2_floats_per_point(), device=dev)
         work, nbytes = scatter_workspace(P, sizes, dev)
-        L.check(lib.nerf_mlp_ngp_bwd(L.ptr(xc), L.ptr(d_rgb), L.ptr(d_sigma), P, L.int_array(res), L.int_array(sizes),
-                                     L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(ws2),
-                                     L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.ptr(work), nbytes,
-                                     L.stream_of(rgb)), "nerf_mlp_ngp_bwd")
+
+        def run(phases):
+            L.check(lib.nerf_mlp_ngp_bwd(L.ptr(xc), L.ptr(d_rgb), L.ptr(d_sigma), P, L.int_array(res), L.int_array(sizes),
+                                         L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(ws2),
+                                         L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.ptr(work), nbytes, phases,
+                                         L.stream_of(rgb)), "nerf_mlp_ngp_bwd")
+
         if sink is not None:
-            sink.done(ctx.params)
+            # the table gradients (41.7 MB, the one sizeable exchange of data-parallel training) are complete after the
+            # first phase: reported now, their all-reduce runs under the weight-gradient kernels of the second
+            run(1)
+            sink.done(ctx.params[:16])
+            run(2)
+            sink.done(ctx.params[16:])
             return (None,) * (5 + len(grads))
+        run(3)
         return (None, None, None, None, None, *grads)
 
 

@@ -153,13 +153,15 @@ def test_gradient_sink_waits_for_every_op_call_of_a_bucket():
     gb.expect(a)
     gb.done(a)
     assert gb._sent == [False, False] and gb._pending == [0, 0]
-    # the last chunk: two op calls on the same parameters
+    # the last chunk: two op calls on the same parameters, the second delivering in two parts
     gb.expect(a)
     gb.expect(a)
     gb.arm()
     gb.done(a)
     assert gb._sent == [False, False]
-    gb.done(a)
+    gb.done(a[:1])
+    assert gb._sent == [False, False]
+    gb.done(a[1:])
     assert gb._sent == [True, False]
     gb.finish()
     assert gb._sent == [True, True]

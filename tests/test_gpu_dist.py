@@ -50,3 +50,49 @@ def test_bucketed_chunked_step_under_nccl_matches_plain_step(dev):
             assert err <= 2e-5 * float(r.double().norm()) + 1e-12, err
     finally:
         dist.destroy_process_group()
+
+
+def test_hash_grid_step_sends_the_tables_before_the_weight_gradients(dev):
+    """The hash-grid model's backward reports its table gradients after the scatter and its MLP gradients after the
+    weight-gradient kernels; with buckets [tables], [MLP parameters] the tables' all-reduce is therefore issued
+    between the two phases (and runs under the second).  One rank under RCCL: the sums are identities, so the
+    gradients must equal those of the plain step -- which holds only if each collective is ordered behind the
+    kernels that fill its bucket -- and the order of the sends is recorded."""
+    from nerf_amd import render
+    from nerf_amd.dist import GradBuckets
+    from nerf_amd.models.FastNGPNeRF import FastNGPNeRF
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(5)
+        model = FastNGPNeRF().to(dev)
+        R = 2048
+        g = torch.Generator().manual_seed(6)
+        o = (torch.rand(R, 3, generator=g) * 0.2 - 0.1).to(dev)
+        d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+        tgt = torch.rand(R, 3, generator=g).to(dev)
+        t_rand = torch.rand(R, 64, generator=g).to(dev)
+        kw = dict(t_rand=t_rand, loss_fn=render.ngp_loss)
+        for p in model.parameters():
+            p.grad = None
+        loss_ref = render.train_step(model, o, d, tgt, 0.05, 1.2, 64, **kw)
+        ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+        tables = list(model.hash_encoder.parameters())
+        rest = [p for n, p in model.named_parameters() if not n.startswith("hash_encoder")]
+        gb = GradBuckets([tables, rest], always_reduce=True)
+        order = []
+        send = gb._send
+        gb._send = lambda bi: (order.append((bi, list(gb._pending))), send(bi))[1]
+        for _ in range(2):
+            order.clear()
+            loss = render.train_step(model, o, d, tgt, 0.05, 1.2, 64, buckets=gb, **kw)
+        torch.cuda.synchronize()
+        assert [bi for bi, _ in order] == [0, 1]            # tables first
+        assert order[0][1][1] > 0                           # ... while the MLP parameters' deliveries were still to come
+        assert abs(float(loss) - float(loss_ref)) < 1e-6
+        for n, p in model.named_parameters():
+            r = ref[n]
+            err = float((p.grad - r).double().norm())
+            assert err <= 2e-5 * float(r.double().norm()) + 1e-12, (n, err)
+    finally:
+        dist.destroy_process_group()
