@@ -169,6 +169,7 @@ __global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const 
     // cell at these resolutions: taken in order, the 16 points of a wave instruction would add to the same rows
     // (same-address LDS atomics run one lane after the other).  Within a round the points are taken in the order of
     // a transposed 16 x 16 block, so that a wave holds points 16 apart.
+    static_assert(HG_LDS_THREADS / 4 == 256, "the transposed order below is that of a 16 x 16 block of points");
     for (int64_t t0 = p_begin; t0 < p_end; t0 += HG_LDS_THREADS / 4) {
         const int li = tid >> 2;
         const int64_t p = t0 + ((li & 15) * 16 + (li >> 4));
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
     // whose records enter the queues at different times.
     // Loads stay coalesced: thread t loads point t and hands it to its owner through the record buffer, which is idle
     // at that point of the loop.
+    static_assert(BIN_PTS == 512, "the mapping below permutes 8 waves x 64 lanes");
     const int pt_in_wg = ((tid & 63) >> 3) * 64 + (tid >> 6) + 8 * (tid & 7);
     const int64_t p = (int64_t)blockIdx.x * BIN_PTS + pt_in_wg;
     const bool valid = p < P;

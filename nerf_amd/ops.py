@@ -369,6 +369,8 @@ def zero_grads_like(shapes, device):
 # anyway, so while a sink is installed (grad_sink(...): accumulate_step does it for its GradBuckets) they
 # accumulate straight into the tensors the sink names -- the buckets' p.grad views -- and autograd receives no
 # gradient for those parameters; the sink is told afterwards, in place of the post-accumulate hooks.
+# One sink per process at a time (backward runs on autograd's threads, so it cannot be thread-local): two training
+# steps running concurrently in one process must not both install one.
 _GRAD_SINK = None
 
 
