@@ -304,12 +304,13 @@ def kernel_roofline(model, rays, dev):
     peak_mfma = PEAK_F16_MATRIX_TFLOPS / MFMA_PER_PRODUCT
     # HBM bytes per launch of that kernel from the committed PMC passes (measured
     # offline with rocprofv3 --pmc: a counter run cannot be nested inside this one)
-    traffic = None
+    traffic, busy = None, {}
     try:
         with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as fh:
             tr = json.load(fh)
         if tr.get("points_per_launch") == P and name in tr:
             traffic = tr[name]["hbm_bytes"]
+            busy = {k: tr[k]["mfma_busy"] for k in kernels if k in tr and "mfma_busy" in tr[k]}
     except (OSError, ValueError, KeyError):
         traffic = None
     # the kernel is bounded by whichever resource it uses the larger fraction of
@@ -329,6 +330,10 @@ def kernel_roofline(model, rays, dev):
             "note_six": "until the middle of round 2 a product was six bf16 MFMAs (roofline 416.7 fp32-equivalent TFLOP/s, kernels at "
                         "0.49-0.54 of it); halving the MFMAs per product halves the executed-MFMA fraction of the same time, so "
                         "the fp32-equivalent rate against that earlier roofline is given for comparison",
+            "mfma_busy_pmc": busy or None,
+            "note_busy": "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD of the committed rocprofv3 counter pass "
+                         "(profiles/roofline_traffic.json): the share of the kernel's own clocks (1.6-2.0 GHz under this load, not "
+                         "the 2.4 GHz of the peak) during which the matrix pipe was busy",
             "all_kernels": per_kernel,
             "all_kernels_ms": {k: v[0] * 1e3 for k, v in kernels.items()}}
 
