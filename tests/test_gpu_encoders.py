@@ -143,3 +143,24 @@ def test_binned_scatter_survives_a_full_queue(dev):
     (O.hash_encode(x.double(), tabs, res) * d_out.double()).sum().backward()
     for l, (a, t) in enumerate(zip(binned, tabs)):
         assert rel_err(a.cpu(), t.grad) < 5e-5, l
+
+
+def test_scatter_workspace_is_checked(dev):
+    """A workspace that is too small or not 16-byte aligned is refused with a message before anything is launched."""
+    from nerf_amd import _lib as L, ops
+    res, sizes = O.hash_resolutions(), O.hash_table_sizes(O.hash_resolutions())
+    P = 70000
+    x = torch.rand(P, 3, device=dev)
+    d_out = torch.randn(P, 32, device=dev)
+    grads = [torch.zeros(s, 2, device=dev) for s in sizes]
+    work, nbytes = ops.scatter_workspace(P, sizes, dev)
+    args = lambda w, n: (L.ptr(x), P, L.ptr(d_out), L.int_array(res), L.int_array(sizes), 16, L.ptr_array(grads), w, n,
+                         L.stream_of(x))
+    with pytest.raises(L.NerfHipError, match="needed"):
+        L.check(L.lib().nerf_hashgrid_bwd(*args(L.ptr(work), nbytes // 2)), "nerf_hashgrid_bwd")
+    with pytest.raises(L.NerfHipError, match="aligned"):
+        L.check(L.lib().nerf_hashgrid_bwd(*args(work.data_ptr() + 4, nbytes)), "nerf_hashgrid_bwd")
+    torch.cuda.synchronize()
+    assert all(float(g.abs().max()) == 0.0 for g in grads)          # nothing was launched
+    L.check(L.lib().nerf_hashgrid_bwd(*args(L.ptr(work), nbytes)), "nerf_hashgrid_bwd")
+    assert float(grads[-1].abs().max()) > 0.0

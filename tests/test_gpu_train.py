@@ -527,3 +527,33 @@ def test_fused_render_loss_matches_the_tensor_ops(dev):
                 # the regulariser's gradient is a sign: rays whose weights sum to 1 within rounding may take either
                 bad = (x.grad - y.grad).abs() > 2e-6 * scale + 1e-12
                 assert int(bad.sum()) <= (N if reg else 0), (R, N, with_fine, reg, int(bad.sum()))
+
+
+def test_one_model_in_both_passes_accumulates_straight_into_the_buckets(dev):
+    """fine_model = the coarse model: two calls of the fused op on the same parameters in one backward pass.  With
+    buckets the two calls accumulate straight into the same flat buffer (ops.grad_sink); the result must be the sum
+    autograd forms without buckets."""
+    from nerf_amd.dist import GradBuckets
+    from nerf_amd.models.NeRF import NeRF
+    from nerf_amd.render import train_step
+    torch.manual_seed(9)
+    model = NeRF().to(dev)
+    R = 512
+    gen = torch.Generator().manual_seed(10)
+    o = torch.tensor([0.0, 0.0, 4.0]).expand(R, 3).contiguous().to(dev)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen) * torch.tensor([0.3, 0.3, 0.0]) +
+                                      torch.tensor([0.0, 0.0, -1.0]), dim=-1).to(dev)
+    gt = torch.rand(R, 3, generator=gen).to(dev)
+    kw = dict(t_rand=torch.rand(R, 64, generator=gen).to(dev), u_fine=torch.rand(R, 128, generator=gen).to(dev),
+              white_bkgd=True, fine_model=model, n_importance=128)
+    loss_ref = train_step(model, o, d, gt, 2.0, 6.0, 64, **kw)
+    ref = [p.grad.clone() for p in model.parameters()]
+    gb = GradBuckets([list(model.parameters())])
+    for chunk in (R, 128):
+        loss = train_step(model, o, d, gt, 2.0, 6.0, 64, buckets=gb, chunk_rays=chunk, **kw)
+        assert abs(float(loss) - float(loss_ref)) < 1e-6
+        assert gb._sent == [True] and gb._pending == [0]
+        for p, r in zip(model.parameters(), ref):
+            assert p.grad.data_ptr() == gb.views[0][[id(q) for q in gb.buckets[0]].index(id(p))].data_ptr()
+            err = float((p.grad - r).double().norm())
+            assert err <= 2e-5 * float(r.double().norm()) + 1e-12, (chunk, tuple(p.shape), err)
