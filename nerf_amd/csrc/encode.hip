@@ -159,7 +159,7 @@ __global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const 
                                                                           const float* __restrict__ d_out, float* tab,
                                                                           int res, unsigned size, int l, int levels,
                                                                           int64_t level_stride) {
-    extern __shared__ double s_tab[];   // [size][2]
+    extern __shared__ double s_tab[];   // [2][size]: feature-major (two atomics on the adjacent doubles of a row collide)
     const int tid = threadIdx.x;
     for (unsigned i = tid; i < 2 * size; i += HG_LDS_THREADS) s_tab[i] = 0.0;
     __syncthreads();
@@ -183,12 +183,12 @@ __global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const 
         for (int yz = 0; yz < 4; ++yz) {
             const unsigned row = hash_row(px, (yz & 2) ? c.hi[1] : c.lo[1], (yz & 1) ? c.hi[2] : c.lo[2], size);
             const float wgt = (wx * ((yz & 2) ? c.w[1] : 1.0f - c.w[1])) * ((yz & 1) ? c.w[2] : 1.0f - c.w[2]);
-            atomicAdd(s_tab + 2 * row + f, (double)(wgt * g));
+            atomicAdd(s_tab + f * size + row, (double)(wgt * g));
         }
     }
     __syncthreads();
     for (unsigned i = tid; i < 2 * size; i += HG_LDS_THREADS) {
-        const float v = (float)s_tab[i];
+        const float v = (float)s_tab[(i & 1) * size + (i >> 1)];
         if (v != 0.0f) atomicAdd(tab + i, v);
     }
 }
@@ -382,9 +382,13 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
 }
 
 constexpr int RED_THREADS = 1024;
+constexpr unsigned RED_F1 = BIN_SEG_ROWS + 2;   // doubles from a row's feature 0 to its feature 1 in the LDS image
 __global__ __launch_bounds__(RED_THREADS) void hashgrid_reduce_kernel(BinLevels lv, const unsigned* __restrict__ counters,
                                                                       const float4* __restrict__ queues) {
-    extern __shared__ double s_tab[];   // [BIN_SEG_ROWS + 2][2]: a record's second row may be the one past the segment
+    // The image is feature-major, [2][BIN_SEG_ROWS + 2] (a record's second row may be the one past the segment): two
+    // atomics on the adjacent doubles of an interleaved row cost 69 ticks where two on independent doubles cost 52
+    // (tools/microbench/lds_atomic.hip).
+    extern __shared__ double s_tab[];
     typedef float f32x4n __attribute__((ext_vector_type(4)));
     int j = 0;
 #pragma unroll 1
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(RED_THREADS) void hashgrid_reduce_kernel(BinLevels 
     const unsigned row0 = (unsigned)sg * BIN_SEG_ROWS;
     const unsigned rows = min((unsigned)BIN_SEG_ROWS, lv.size[j] - row0);
     const int tid = threadIdx.x;
-    for (unsigned i = tid; i < 2 * rows + 2; i += RED_THREADS) s_tab[i] = 0.0;
+    for (unsigned i = tid; i < 2 * RED_F1; i += RED_THREADS) s_tab[i] = 0.0;
     __syncthreads();
     const f32x4n* __restrict__ q = reinterpret_cast<const f32x4n*>(queues + lv.q_off[j] + ((size_t)sg * nsub + first_sub) * cap);
     const size_t q_stride = (size_t)slices * cap;   // from one of this workgroup's queues to the next
@@ -436,19 +440,19 @@ __global__ __launch_bounds__(RED_THREADS) void hashgrid_reduce_kernel(BinLevels 
         for (int u = 0; u < UNR; ++u) {
             const unsigned loc = __float_as_uint(r[u][0]);
             if (loc < BIN_SEG_ROWS) {
-                double* row = s_tab + 2 * loc;
+                double* row = s_tab + loc;   // feature 0 of the row; feature 1 is RED_F1 doubles on
                 const double a = (double)r[u][1], b = (double)r[u][2], rho = (double)r[u][3];
                 atomicAdd(row, a);
-                atomicAdd(row + 1, b);
-                atomicAdd(row + 2, a * rho);
-                atomicAdd(row + 3, b * rho);
+                atomicAdd(row + RED_F1, b);
+                atomicAdd(row + 1, a * rho);
+                atomicAdd(row + RED_F1 + 1, b * rho);
             }
         }
     }
     __syncthreads();
     float* __restrict__ tab = lv.table[j] + 2 * (size_t)row0;
     for (unsigned i = tid; i < 2 * rows; i += RED_THREADS) {
-        const float v = (float)s_tab[i];
+        const float v = (float)s_tab[(i & 1) * RED_F1 + (i >> 1)];
         if (v != 0.0f) atomicAdd(tab + i, v);
     }
 }
