@@ -120,6 +120,7 @@ def build_step(kind, rank, rays, dev, chunk_rays, capturable=False):
         opt.step()
         return loss
 
+    step.opt = opt
     return step, model
 
 
@@ -130,7 +131,7 @@ def build_ngp_step(rank, rays, dev, chunk_rays, world, use_graph):
         try:
             from nerf_amd.graph import GraphedStep
             eager, model = build_step("ngp", rank, rays, dev, chunk_rays, capturable=True)
-            return GraphedStep(eager, warmup=3), model, {"hip_graph": True}
+            return GraphedStep(eager, warmup=3, optimizers=[eager.opt]), model, {"hip_graph": True}
         except Exception as e:   # the same kernels run eagerly; the line says so
             try:
                 torch.cuda.synchronize()

@@ -266,18 +266,26 @@ int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, i
 int nerf_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, int64_t step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, void* stream);
-/* The same step with the step count in device memory, for a training step that is captured into a
- * HIP graph and replayed: a count passed by value would be frozen into the graph.  No counterpart in
- * the reference, whose loops step torch.optim.Adam eagerly (torch's own name for this mode is
+/* The same step with the step count AND the learning rate in device memory, for a training step
+ * that is captured into a HIP graph and replayed: a count or a rate passed by value would be frozen
+ * into the graph, and the reference's loops change the rate every epoch (ExponentialLR
+ * src/train_nerf.py:87,204; StepLR src/train_nerf_llff.py:83,183; ReduceLROnPlateau and
+ * CosineAnnealingLR src/train_nerf_ngp.py:57-62,373-379).  The mode itself has no counterpart in the
+ * reference, whose loops step torch.optim.Adam eagerly (torch's own name for it is
  * Adam(capturable=True)).  step_state: 4 device floats, [0] = steps taken so far (0 before the first
- * step; integers are exact in a float up to 2^24 steps).  Every call adds 1 to it (a one-thread
- * launch in front of the update, which also leaves sqrt(1 - beta2^step) in [1] and
- * -lr / (1 - beta1^step) in [2]) and applies the update for that step.  Neither the host nor the
- * call reads anything back. */
+ * step; integers are exact in a float up to 2^24 steps), [3] = the learning rate, written by
+ * nerf_adam_set_lr.  Every call adds 1 to [0] (a one-thread launch in front of the update, which
+ * also leaves sqrt(1 - beta2^step) in [1] and -lr / (1 - beta1^step) in [2]) and applies the update
+ * for that step.  Neither the host nor the call reads anything back. */
 int nerf_adam_step_capturable(int count, float* const* params, const float* const* grads,
                               float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
-                              float* step_state, float lr, float beta1, float beta2, float eps,
+                              float* step_state, float beta1, float beta2, float eps,
                               float weight_decay, void* stream);
+/* step_state[3] = lr, by a one-thread launch on `stream` (what an LR scheduler's step amounts to
+ * for a captured optimiser: optimizer.param_groups[k]["lr"] = ..., src/train_nerf.py:204).  Call it
+ * before the first step and whenever the rate changes, in front of a graph replay on the replay's
+ * stream -- not inside a capture, where the value would become part of the graph. */
+int nerf_adam_set_lr(float* step_state, float lr, void* stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_norm) with the 2-norm (src/train_nerf.py:165):
  * total = the norm of all gradients together, every gradient is multiplied by

@@ -52,7 +52,8 @@ SIGNATURES = {
     "nerf_render_loss_fwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "nerf_render_loss_bwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
     "nerf_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
-    "nerf_adam_step_capturable": (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P]),
+    "nerf_adam_step_capturable": (_I, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P]),
+    "nerf_adam_set_lr": (_I, [_P, _F, _P]),
     "nerf_clip_grad_norm_workspace_floats": (C.c_size_t, [_I, _P]),
     "nerf_clip_grad_norm": (_I, [_I, _P, _P, _F, _P, _P, _P]),
     "nerf_clip_grad_norm_static": (_I, [_I, _P, _P, _F, _P, _P]),

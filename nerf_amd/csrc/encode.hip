@@ -302,7 +302,9 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
         __syncthreads();
         const float2 g = reinterpret_cast<const float2*>(s_xch)[pt_in_wg];
         const Cell c = locate3(xyz, lv.res[j]);
-        const float rho = c.w[0] / (1.0f - c.w[0]);   // w is a fractional part: 1 - w > 0
+        // w = pos - floor(pos) is a fractional part, but for pos in [-2^-25, 0) it rounds to exactly 1: rho = inf
+        // there, and such a corner pair never takes the (a, rho a) record form (`pair` below)
+        const float rho = c.w[0] / (1.0f - c.w[0]);
         unsigned seg[4], pos[4], loc[4];
         float va[4], vb[4], vr[4];
 #pragma unroll
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
             const float w_lo = ((1.0f - c.w[0]) * wy) * wz, w_hi = (c.w[0] * wy) * wz;
             seg[yz] = r_lo / BIN_SEG_ROWS;
             loc[yz] = r_lo % BIN_SEG_ROWS;
-            const bool pair = r_hi == r_lo + 1 && loc[yz] != BIN_SEG_ROWS - 1;
+            const bool pair = r_hi == r_lo + 1 && loc[yz] != BIN_SEG_ROWS - 1 && c.w[0] < 1.0f;
             va[yz] = w_lo * g.x;
             vb[yz] = w_lo * g.y;
             vr[yz] = pair ? rho : 0.0f;

@@ -97,16 +97,24 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float b1m, flo
     }
 }
 
-// The step count of an optimiser whose launches are replayed from a HIP graph cannot be a kernel argument (it
-// would be frozen into the graph): state[0] holds it in device memory.  One thread advances it and derives the two
-// step-dependent scalars the way the host does for nerf_adam_step (in double, rounded to float).
-__global__ void adam_advance_kernel(float* __restrict__ state, float lr, float beta1, float beta2) {
+// Neither the step count nor the learning rate of an optimiser whose launches are replayed from a HIP graph can be
+// a kernel argument (it would be frozen into the graph, and the reference's loops change the rate every epoch:
+// src/train_nerf.py:87,204, src/train_nerf_ngp.py:57-62,373-379): state[0] holds the count and state[3] the rate in
+// device memory.  One thread advances the count and derives the two step-dependent scalars the way the host does
+// for nerf_adam_step (in double, rounded to float).
+__global__ void adam_advance_kernel(float* __restrict__ state, float beta1, float beta2) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double step = (double)state[0] + 1.0;
     const double bias1 = 1.0 - pow((double)beta1, step), bias2 = 1.0 - pow((double)beta2, step);
     state[0] = (float)step;
     state[1] = (float)sqrt(bias2);
-    state[2] = (float)(-((double)lr / bias1));
+    state[2] = (float)(-((double)state[3] / bias1));
+}
+
+// The rate arrives as a kernel argument and leaves by a vector store: no host buffer that a replayed graph could
+// outlive, and ordered on the stream like any launch (issued in front of a replay, never inside a capture).
+__global__ void adam_set_lr_kernel(float* __restrict__ state, float lr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[3] = lr;
 }
 
 // ---------------------------------------------------------------------------
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(float* __restrict__ scra
         const float total = (float)sqrt(s_part[0]);
         const float coef = max_norm / (total + 1e-6f);
         scratch[0] = total;
-        scratch[1] = coef < 1.0f ? coef : 1.0f;
+        scratch[1] = (coef < 1.0f || coef != coef) ? coef : 1.0f;   // a NaN norm reaches every gradient, as torch's clamp lets it
         if (total_out) *total_out = total;
     }
 }
@@ -277,7 +285,7 @@ static int adam_run(const char* who, int count, float* const* params, const floa
     const float b1m = (float)(1.0 - (double)beta1), b2m = (float)(1.0 - (double)beta2);
     float bias2_sqrt = 1.0f, neg_step = 0.0f;
     if (step_state) {
-        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, stream, step_state, lr, beta1, beta2);
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, stream, step_state, beta1, beta2);
         if (int rc = check_launch(who)) return rc;
     } else {
         const double bias1 = 1.0 - pow((double)beta1, (double)step), bias2 = 1.0 - pow((double)beta2, (double)step);
@@ -317,13 +325,20 @@ extern "C" int nerf_adam_step(int count, float* const* params, const float* cons
 }
 
 extern "C" int nerf_adam_step_capturable(int count, float* const* params, const float* const* grads, float* const* exp_avg,
-                                         float* const* exp_avg_sq, const int64_t* numel, float* step_state, float lr,
+                                         float* const* exp_avg_sq, const int64_t* numel, float* step_state,
                                          float beta1, float beta2, float eps, float weight_decay, void* stream) {
     NERF_REQUIRE(step_state, "nerf_adam_step_capturable: null step state");
     NERF_REQUIRE(count >= 0 && (count == 0 || (params && grads && exp_avg && exp_avg_sq && numel)),
                  "nerf_adam_step_capturable: null pointer");
-    return adam_run("nerf_adam_step_capturable", count, params, grads, exp_avg, exp_avg_sq, numel, 0, step_state, lr, beta1,
+    return adam_run("nerf_adam_step_capturable", count, params, grads, exp_avg, exp_avg_sq, numel, 0, step_state, 0.0f, beta1,
                     beta2, eps, weight_decay, (hipStream_t)stream);
+}
+
+extern "C" int nerf_adam_set_lr(float* step_state, float lr, void* stream) {
+    NERF_REQUIRE(step_state, "nerf_adam_set_lr: null step state");
+    NERF_REQUIRE(lr >= 0.0f, "nerf_adam_set_lr: lr=%g", (double)lr);
+    hipLaunchKernelGGL(adam_set_lr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_state, lr);
+    return check_launch("nerf_adam_set_lr");
 }
 
 extern "C" size_t nerf_clip_grad_norm_workspace_floats(int count, const int64_t* numel) {

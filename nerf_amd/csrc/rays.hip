@@ -257,8 +257,8 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
 
     for (int k = lane; k < Nc; k += 64) s_zc[wv][k] = zr[k];
     float* cdf;
-    if (nw <= 64) {
-        // One weight per lane: the log-step inclusive scan runs in registers, each step one wavefront shuffle
+    if (nb <= 64) {
+        // One weight and one cdf entry per lane (nb = nw + 1 entries: with nw = 64 the last entry would have no lane): the log-step inclusive scan runs in registers, each step one wavefront shuffle
         // (lane k adds the value of lane k - d).  The association order is part of the contract: the CPU
         // oracle performs the same additions.
         float v = lane < nw ? wr[lane + 1] + 1e-5f : 0.0f;

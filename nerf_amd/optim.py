@@ -8,10 +8,13 @@ loops use, same update rule, and a ``state_dict`` with torch's keys
 form (src/train_nerf_llff.py:82, src/train_nerf_skow.py:47 use 1e-6); amsgrad and maximize are
 not implemented and raise.  ``clip_grad_norm_`` (src/train_nerf.py:165) lives in ``nerf_amd.ops``.
 
-``capturable=True`` (torch's name for it) keeps the step count in device memory, so that a whole training
-step -- this optimiser's launch included -- can be captured into a HIP graph and replayed
+``capturable=True`` (torch's name for it) keeps the step count AND the learning rate in device memory, so that a
+whole training step -- this optimiser's launch included -- can be captured into a HIP graph and replayed
 (``nerf_amd.graph.GraphedStep``): ``state[p]["step"]`` is then a float32 scalar on the GPU, as with
-``torch.optim.Adam(capturable=True)``, shared by the parameters of a group.
+``torch.optim.Adam(capturable=True)``, shared by the parameters of a group.  ``group["lr"]`` stays the Python
+float that ``torch.optim.lr_scheduler.*`` reads and writes (ExponentialLR src/train_nerf.py:87,204, StepLR
+src/train_nerf_llff.py:83, ReduceLROnPlateau / CosineAnnealingLR src/train_nerf_ngp.py:57-62); ``sync_lr()`` -- called
+by every eager ``step()`` and by ``GraphedStep`` in front of every replay -- sends it to the device when it changed.
 """
 from __future__ import annotations
 
@@ -31,7 +34,8 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False,
                                       maximize=False, capturable=bool(capturable)))
-        self._dev_state = {}   # capturable groups: index -> 4 device floats, [0] = steps taken
+        self._dev_state = {}   # capturable groups: index -> 4 device floats, [0] = steps taken, [3] = learning rate
+        self._dev_lr = {}      # capturable groups: index -> the rate the device holds
 
     def _capturable_state(self, gi: int, ps) -> torch.Tensor:
         """The group's step state in device memory; every parameter's ``state["step"]`` is the same 0-d view of
@@ -50,9 +54,38 @@ class FusedAdam(torch.optim.Optimizer):
                 self.state[p]["step"] = view
         return dev
 
+    def sync_lr(self) -> None:
+        """Send every capturable group's ``lr`` to its device state if it differs from what the device holds (one
+        one-thread launch per changed group on the current stream, nothing when unchanged).  Under stream capture
+        nothing may be written -- the value would be replayed with the graph -- so a rate that changed since the last
+        eager step raises there instead of training on silently with the old one."""
+        for gi, group in enumerate(self.param_groups):
+            entry = self._dev_state.get(gi)
+            if entry is None or not group.get("capturable", False):
+                continue
+            lr = float(group["lr"])
+            if self._dev_lr.get(gi) == lr:
+                continue
+            dev = entry[0]
+            if torch.cuda.is_current_stream_capturing():
+                raise L.NerfHipError("FusedAdam: the learning rate changed between the last eager step and a stream "
+                                     "capture; call sync_lr() before capturing")
+            L.check(L.lib().nerf_adam_set_lr(L.ptr(dev), lr, L.stream_of(dev)), "nerf_adam_set_lr")
+            self._dev_lr[gi] = lr
+
+    def state_dict(self):
+        """torch's layout.  The parameters of a capturable group share one step tensor; the dict gets a copy per
+        parameter, so that an optimiser which advances each parameter's step by itself (this class without
+        ``capturable``, ``torch.optim.Adam``) can load it."""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (v.clone() if n == "step" and torch.is_tensor(v) else v) for n, v in st.items()}
+                       for k, st in sd["state"].items()}
+        return sd
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._dev_state = {}   # rebuilt from the loaded step counts on the next step
+        self._dev_lr = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -78,12 +111,13 @@ class FusedAdam(torch.optim.Optimizer):
             if group.get("capturable", False):
                 # one launch pair for the group, nothing read back, no host-side step count
                 dev = self._capturable_state(gi, ps)
+                self.sync_lr()
                 n = len(ps)
                 numel = (C.c_int64 * n)(*[p.numel() for p in ps])
                 L.check(L.lib().nerf_adam_step_capturable(
                     n, L.ptr_array(ps), L.ptr_array([L.f32c(p.grad) for p in ps]),
                     L.ptr_array([self.state[p]["exp_avg"] for p in ps]),
-                    L.ptr_array([self.state[p]["exp_avg_sq"] for p in ps]), numel, L.ptr(dev), group["lr"],
+                    L.ptr_array([self.state[p]["exp_avg_sq"] for p in ps]), numel, L.ptr(dev),
                     group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
                     L.stream_of(ps[0])), "nerf_adam_step_capturable")
                 continue

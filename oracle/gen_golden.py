@@ -2,7 +2,7 @@
 
 Run only in the development container, where the reference checkout exists:
 
-    MPLBACKEND=Agg python oracle/gen_golden.py [/root/reference [g1 g2 ... g9]]
+    MPLBACKEND=Agg python oracle/gen_golden.py [/root/reference [g1 g2 ... g10]]
 
 The outputs are small input/output vectors of the reference's own functions
 (plus per-parameter checksums proving that seeded construction gives the same
@@ -398,6 +398,101 @@ def g9(steps=320, ckpt=None):
          loss=np.array(losses), grad_norm=np.array(norms), psnr_steps=np.array(marks), psnr=np.array(psnrs))
 
 
+# ---------------------------------------------------------------- G10 training trajectories under LR schedules
+def g10():
+    """Two short runs of the reference's own pieces with the learning-rate schedules its loops use.
+    (a) NeRF() on the analytic scene at 50 x 50 rays, 64 samples, epochs of 8 views: Adam(lr=5e-4),
+    clip_grad_norm_(1.0), ExponentialLR(gamma=0.98) stepped once per epoch (src/train_nerf.py:86-87,165,204),
+    80 steps.  (b) FastNGPNeRF() on the same field shrunk into the unit cube at 32 x 32 rays, 64 samples, epochs of
+    2 views: Adam(lr=1e-2, eps=1e-15), loss = mse + 0.05 mean|1 - sum w| (src/train_nerf_ngp.py:55,221-222),
+    CosineAnnealingLR(T_max=30, eta_min=1e-4) stepped once per epoch (:62,375), 40 steps, float32 (the loop's
+    autocast is CUDA-only).  Recorded: the loss and the learning rate of every step."""
+    import contextlib
+    import io
+    import time
+    up = torch.tensor([0.0, 0.0, 1.0])
+
+    def make_views(count, radius, height, focal, H, W, near, far, n, shrink, boost):
+        cams, rays, imgs = [], [], []
+        for a in torch.linspace(0, 2 * torch.pi, steps=count + 1)[:count]:
+            eye = torch.tensor([radius * np.cos(float(a)), radius * np.sin(float(a)), height], dtype=torch.float32)
+            cam = Camera(eye=eye, target=2 * eye, focal=focal, H=H, W=W, up=up)   # faces the origin (see g9)
+            ro, rd = cam.get_rays()
+            pts, z = Camera.sample_points_along_rays(ro, rd, near, far, n, perturb=False)
+            rgb, sigma = legacy.evaluate_fake_radiance_field_complex(pts * shrink)
+            img, _ = Camera.volume_render(rgb, sigma * boost, z)
+            cams.append(cam); rays.append((ro, rd)); imgs.append(img)
+        return cams, rays, imgs
+
+    def render(model, ro, rd, near, far, n, chunk):
+        H, W = ro.shape[:2]
+        pts, z = Camera.sample_points_along_rays(ro, rd, near, far, n, perturb=True)
+        vd = (rd / rd.norm(dim=-1, keepdim=True))[:, :, None, :].expand(H, W, n, 3)
+        pf, vf = pts.reshape(-1, 3), vd.reshape(-1, 3)
+        rgbs, sigmas = [], []
+        for i in range(0, pf.shape[0], chunk):
+            r, s = model(pf[i:i + chunk], vf[i:i + chunk])
+            rgbs.append(r); sigmas.append(s)
+        return Camera.volume_render(torch.cat(rgbs).view(H, W, n, 3), torch.cat(sigmas).view(H, W, n), z)
+
+    out = {}
+    t0 = time.time()
+    # (a) vanilla + ExponentialLR
+    H = W = 50
+    n, near, far, boost, views, steps = 64, 1.0, 5.0, 5.0, 8, 80
+    cams, rays, imgs = make_views(views, 2.0, 2.0, (50.0, 50.0), H, W, near, far, n, 1.0, boost)
+    torch.manual_seed(0)
+    model = NeRF()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.98)
+    losses, lrs = [], []
+    for step in range(steps):
+        v = step % views
+        torch.manual_seed(2000 + step)
+        with contextlib.redirect_stdout(io.StringIO()):
+            img, _ = render(model, rays[v][0], rays[v][1], near, far, n, 65536)
+        loss = torch.nn.functional.mse_loss(img, imgs[v])
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        losses.append(float(loss.detach()))
+        if v == views - 1:
+            sched.step()
+        if (step + 1) % 8 == 0:
+            print(f"g10a step {step + 1}: loss {losses[-1]:.6f} lr {lrs[-1]:.6e} ({time.time() - t0:.0f}s)", flush=True)
+    out.update(a_c2w=torch.stack([c.c2w for c in cams]), a_cfg=np.array([H, W, 50.0, near, far, n, boost, views, 1.0]),
+               a_img_sum=np.array([float(i.double().sum()) for i in imgs]), a_loss=np.array(losses), a_lr=np.array(lrs))
+    # (b) hash-grid model + CosineAnnealingLR
+    H = W = 32
+    n, near, far, shrink, views, steps = 64, 0.05, 1.6, 2.5, 2, 40
+    boost = 5.0 * shrink
+    cams, rays, imgs = make_views(views, 0.8, 0.5, (32.0, 32.0), H, W, near, far, n, shrink, boost)
+    torch.manual_seed(0)
+    model = FastNGPNeRF()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, eps=1e-15)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=30, eta_min=1e-4)
+    losses, lrs = [], []
+    for step in range(steps):
+        v = step % views
+        torch.manual_seed(3000 + step)
+        img, w = render(model, rays[v][0], rays[v][1], near, far, n, 16384)
+        loss = torch.nn.functional.mse_loss(img, imgs[v]) + 0.05 * (1 - w.sum(dim=-1)).abs().mean()
+        opt.zero_grad()
+        loss.backward()
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        losses.append(float(loss.detach()))
+        if v == views - 1:
+            sched.step()
+        if (step + 1) % 8 == 0:
+            print(f"g10b step {step + 1}: loss {losses[-1]:.6f} lr {lrs[-1]:.6e} ({time.time() - t0:.0f}s)", flush=True)
+    out.update(b_c2w=torch.stack([c.c2w for c in cams]), b_cfg=np.array([H, W, 32.0, near, far, n, boost, views, shrink]),
+               b_img_sum=np.array([float(i.double().sum()) for i in imgs]), b_loss=np.array(losses), b_lr=np.array(lrs))
+    save("g10_sched.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = [a for a in sys.argv[2:]] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]   # g9 takes ~40 min: by name only
@@ -410,3 +505,4 @@ if __name__ == "__main__":
     if "g7" in which: g7()
     if "g8" in which: g8()
     if "g9" in which: g9()
+    if "g10" in which: g10()

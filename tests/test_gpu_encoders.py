@@ -111,11 +111,17 @@ def test_binned_scatter_matches_direct_atomics_and_oracle(dev):
     P = 70001                                               # above the binning threshold, not a multiple of anything
     x = torch.rand(P, 3, generator=gen) * 2.4 - 1.2
     x[:64] = torch.tensor([0.999999, -1.0, 0.5])            # many points in one cell: one segment gets a run of equal rows
+    # coordinates just below zero: x * res - floor(x * res) rounds to exactly 1, the low-x weight to 0 and their ratio
+    # to infinity -- such corners must take the direct path, or 0 * inf would poison the table gradient
+    x[64:128, 0] = -1e-9
+    x[128:192] = torch.tensor([-1e-10, -3e-9, -1e-12])
+    x[192:256, 0] = -(2.0 ** -26) / torch.tensor(res, dtype=torch.float32).repeat(4)
     d_out = torch.randn(P, 32, generator=gen)
     xd, dd = x.to(dev), d_out.to(dev)
     direct = _scatter(dev, xd, dd, res, sizes, binned=False)
     binned = _scatter(dev, xd, dd, res, sizes, binned=True)
     for l, (a, b) in enumerate(zip(binned, direct)):
+        assert bool(torch.isfinite(a).all()), l
         assert rel_err(a, b) < 2e-6, l
     tabs = [torch.zeros(s, 2, requires_grad=True) for s in sizes]
     (O.hash_encode(x, tabs, res) * d_out).sum().backward()

@@ -93,7 +93,7 @@ def test_raygen_sample_ragged_sizes(dev, R, N):
     assert torch.equal(z3.cpu(), z_n.expand_as(z3.cpu())) and torch.equal(pts3.cpu(), pts_n)
 
 
-@pytest.mark.parametrize("Nc,Nf", [(64, 128), (17, 5), (3, 1), (100, 200), (64, 400), (256, 768)])
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (17, 5), (3, 1), (100, 200), (64, 400), (256, 768), (66, 128), (65, 7), (67, 64)])
 def test_pdf_sample_indices_bit_exact(dev, Nc, Nf):
     from nerf_amd import ops
     gen = torch.Generator().manual_seed(100 + Nc)
@@ -108,6 +108,7 @@ def test_pdf_sample_indices_bit_exact(dev, Nc, Nf):
         w[1, Nc // 2] = 1.0
     u = torch.rand(R, Nf, generator=gen)
     u[2, 0] = 0.0
+    u[3] = 1.0 - 2.0 ** -24                        # the last bin: reads the final cdf entry
     zf_o, idx_o, zall_o = O.sample_pdf(z, w, u)
     zf, idx, z_all, pts = ops.pdf_sample(o.to(dev), d.to(dev), z.to(dev), w.to(dev), u.to(dev), want_idx=True)
     assert torch.equal(idx.cpu(), idx_o)          # sample indices: bit-exact

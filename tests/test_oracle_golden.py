@@ -250,3 +250,43 @@ def test_occupancy_mask_semantics():
     assert out.tolist() == [0.0, 2.0, 0.0, 4.0]
     out.sum().backward()
     assert sigma.grad.tolist() == [0.0, 1.0, 0.0, 1.0]
+
+
+def test_g10_schedule_fixture_rates_scene_and_first_steps():
+    """g10_sched.npz: the learning rates are those of ExponentialLR(0.98) / CosineAnnealingLR(30, 1e-4) stepped per
+    epoch, the ground-truth images are the oracle's, and the oracle's own training step (its NeRF, sampling,
+    compositing, torch Adam and clipping) reproduces the first steps of the vanilla trajectory."""
+    import math
+    g = load_golden("g10_sched.npz")
+    a_lr = np.array([5e-4 * 0.98 ** (s // 8) for s in range(80)])
+    b_lr = np.array([1e-4 + (1e-2 - 1e-4) * (1 + math.cos(math.pi * (s // 2) / 30)) / 2 for s in range(40)])
+    assert np.allclose(g["a_lr"], a_lr, rtol=1e-9) and np.allclose(g["b_lr"], b_lr, rtol=1e-9)
+    scenes = {}
+    for tag in ("a", "b"):
+        H, W, f, near, far, n, boost, views, shrink = [float(v) for v in g[tag + "_cfg"]]
+        H, W, n = int(H), int(W), int(n)
+        rays, imgs = [], []
+        for k in range(int(views)):
+            o, d = O.get_rays(T(g[tag + "_c2w"][k]), (f, f), H, W)
+            pts, z = O.sample_points_along_rays(o, d, near, far, n, None)
+            rgb, sigma = O.analytic_field(pts * shrink)
+            img, _ = O.volume_render(rgb, sigma * boost, z)
+            want = float(g[tag + "_img_sum"][k])
+            assert abs(float(img.double().sum()) - want) < 1e-6 * max(1.0, want), (tag, k)
+            rays.append((o.reshape(-1, 3), d.reshape(-1, 3)))
+            imgs.append(img.reshape(-1, 3))
+        scenes[tag] = (H, W, near, far, n, rays, imgs)
+    H, W, near, far, n, rays, imgs = scenes["a"]
+    torch.manual_seed(0)
+    m = O.NeRFOracle()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    for step in range(2):
+        torch.manual_seed(2000 + step)
+        u = torch.rand(H, W, n).reshape(H * W, n)
+        c_map, _, _, _ = O.render_rays(m, rays[step][0], rays[step][1], near, far, n, t_rand=u, chunk=65536)
+        loss = torch.nn.functional.mse_loss(c_map, imgs[step])
+        assert abs(float(loss) - float(g["a_loss"][step])) < 1e-5 * float(g["a_loss"][step]), step
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0)
+        opt.step()
