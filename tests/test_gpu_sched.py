@@ -223,7 +223,8 @@ def test_capturable_state_loads_into_per_parameter_step_optimisers(dev):
         with torch.no_grad():
             for p, q in zip(ps, a):
                 p.copy_(q)
-    o_b.load_state_dict(sd); o_c.load_state_dict(sd)
+    import copy
+    o_b.load_state_dict(copy.deepcopy(sd)); o_c.load_state_dict(copy.deepcopy(sd))   # (load_state_dict adopts the tensors it is given)
     for it in range(3, 5):
         for ps in (a, b, c, d):
             for p, gr in zip(ps, grads[it]):
@@ -232,4 +233,4 @@ def test_capturable_state_loads_into_per_parameter_step_optimisers(dev):
     assert float(o_b.state[b[0]]["step"]) == 5.0 and float(o_c.state[c[0]]["step"]) == 5.0
     for pa, pb, pc, pd in zip(a, b, c, d):
         for q in (pa, pb, pc):
-            assert torch.allclose(q, pd, rtol=3e-6, atol=1e-7), float((q - pd).abs().max())
+            assert torch.allclose(q, pd, rtol=3e-6, atol=1e-7), float((q.detach() - pd.detach()).abs().max())
