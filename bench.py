@@ -77,7 +77,21 @@ NGP_WORKLOAD = ("Instant-NGP variant (16 levels, 2^19 rows, 64-wide MLPs), 800x8
                 "HIP graph and replayed)")
 
 
-def build_step(kind, rank, rays, dev, chunk_rays, capturable=False):
+def ball_grid(fraction, dev, res=32):
+    """uint8 occupancy grid [res^3] (indexed x + 32 y + 1024 z like the reference's xyz_to_idx): the cells whose centre
+    lies in the ball around the origin that fills `fraction` of the cube [-1, 1]^3 -- a synthetic stand-in for the grid
+    get_density_grid derives from a trained model (src/utils/analyze_capture_results.py:233-248)."""
+    radius = (fraction * 8.0 * 3.0 / (4.0 * math.pi)) ** (1.0 / 3.0)
+    c = (torch.arange(res).float() + 0.5) / res * 2 - 1
+    x, y, z = torch.meshgrid(c, c, c, indexing="ij")
+    occ = (x ** 2 + y ** 2 + z ** 2) < radius ** 2
+    ix, iy, iz = torch.meshgrid(torch.arange(res), torch.arange(res), torch.arange(res), indexing="ij")
+    grid = torch.zeros(res ** 3, dtype=torch.uint8)
+    grid[(ix + iy * 32 + iz * 1024).reshape(-1)] = occ.reshape(-1).to(torch.uint8)
+    return grid.to(dev), float(occ.float().mean())
+
+
+def build_step(kind, rank, rays, dev, chunk_rays, capturable=False, occupancy=None):
     """One training step of the vanilla (coarse + fine 8x256 MLPs, 64 + 128 samples) or hash-grid workload:
     fused ray generation + stratified sampling, chunked forward/backward with the gradients in flat buckets
     (their cross-rank sum starts under the last chunk's backward), fused Adam.  Returns (step, model)."""
@@ -101,6 +115,9 @@ def build_step(kind, rank, rays, dev, chunk_rays, capturable=False):
         z_lin = torch.linspace(NGP_NEAR, NGP_FAR, N_COARSE).to(dev)
         kw = dict(loss_fn=ngp_loss, white_bkgd=False)
         near, far = NGP_NEAR, NGP_FAR
+        if occupancy:
+            grid, cells = ball_grid(occupancy, dev)
+            kw.update(density_grid=grid, grid_res=32, skip_empty=True)
     else:
         from nerf_amd.models.NeRF import NeRF
         torch.manual_seed(0)
@@ -121,17 +138,52 @@ def build_step(kind, rank, rays, dev, chunk_rays, capturable=False):
         return loss
 
     step.opt = opt
+    step.buckets = buckets
+    if kind == "ngp" and occupancy:
+        o, d, z, pts = ops.raygen_sample(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix, z_lin, u_c)
+        step.occupancy = {"grid_cells_occupied": cells, "samples_kept": ops.occupancy_compact(pts, grid, 32)[0].numel() / float(pts.shape[0] * pts.shape[1])}
     return step, model
 
 
-def build_ngp_step(rank, rays, dev, chunk_rays, world, use_graph):
+def dist_info(world, backend, dev, buckets):
+    """Who took part in the run, for the reader of the JSON line: the process group's own world size and backend, the
+    RCCL version, every rank's device (gathered, not assumed) and the bytes each rank's gradient all-reduces carry per
+    step."""
+    import torch.distributed as dist
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": int(os.environ.get("RANK", 0)), "device": dev.index, "name": props.name,
+            "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None}
+    info = {"world": 1, "backend": None, "devices": [mine]}
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        info = {"world": dist.get_world_size(), "backend": dist.get_backend(), "devices": everyone}
+    try:
+        info["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        info["rccl"] = None
+    flats = getattr(buckets, "flats", [])
+    info["allreduce_bytes_per_step"] = [4 * f.numel() for f in flats] if world > 1 else []
+    info["allreduce_note"] = ("one sum all-reduce per gradient bucket (flat fp32 buffer) per step, issued under the last ray "
+                              "chunk's backward; no other collective in the step" if world > 1 else "single rank: no collective")
+    return info
+
+
+def build_ngp_step(rank, rays, dev, chunk_rays, world, use_graph, occupancy=None):
     """The hash-grid step; with use_graph captured into a HIP graph and replayed where that applies: one GPU (no
-    collective inside the step) and one ray chunk.  Returns (step, model, info for the result's config)."""
+    collective inside the step) and one ray chunk.  Returns (step, model, info for the result's config).
+    occupancy: fraction of an occupancy grid's cells that are occupied (a ball); the step then skips the samples in
+    empty cells (sizes depend on the data: issued launch by launch, never from a graph)."""
+    if occupancy:
+        step, model = build_step("ngp", rank, rays, dev, chunk_rays, occupancy=occupancy)
+        return step, model, {"hip_graph": False, "skip_empty": True, **step.occupancy}
     if use_graph and world == 1 and (chunk_rays is None or chunk_rays >= rays) and rays <= 65536:
         try:
             from nerf_amd.graph import GraphedStep
             eager, model = build_step("ngp", rank, rays, dev, chunk_rays, capturable=True)
-            return GraphedStep(eager, warmup=3, optimizers=[eager.opt]), model, {"hip_graph": True}
+            graphed = GraphedStep(eager, warmup=3, optimizers=[eager.opt])
+            graphed.buckets = eager.buckets
+            return graphed, model, {"hip_graph": True}
         except Exception as e:   # the same kernels run eagerly; the line says so
             try:
                 torch.cuda.synchronize()
@@ -192,11 +244,12 @@ def gpu_main(args):
     chunk = args.chunk_rays
     graph_info = {}
     if args.model == "ngp":
-        step, model, graph_info = build_ngp_step(rank, rays, dev, chunk, world, (not args.no_graph))
+        step, model, graph_info = build_ngp_step(rank, rays, dev, chunk, world, (not args.no_graph), args.occupancy)
     else:
         step, model = build_step(args.model, rank, rays, dev, chunk)
     dt, final_loss = timed_steps(step, args.steps, args.warmup, world, dev)
-    secondary = None
+    who = dist_info(world, backend, dev, getattr(step, "buckets", None))   # a collective: every rank calls it
+    secondary = secondary_skip = None
     if args.model == "vanilla" and not args.no_secondary:
         # the hash-grid configuration, same camera and batch size, as a second result in the same line
         del step
@@ -209,6 +262,19 @@ def gpu_main(args):
                          "unit": "rays/s", "n_gpus": world, "steps": n2, "ms_per_step": 1e3 * dt2 / n2, "dtype": "f32",
                          "config": {"workload": NGP_WORKLOAD % rays, "rays_per_gpu": rays, "final_loss": loss2, **graph2},
                          "roofline": ngp_roofline(ngp, min(rays, 65536), dev)}
+        # the same step skipping the samples in empty cells of a synthetic occupancy grid (a third result, beside the others)
+        del step2, ngp
+        torch.cuda.empty_cache()
+        step3, _, info3 = build_ngp_step(rank, rays, dev, chunk, world, False, occupancy=args.occupancy or 0.2)
+        dt3, loss3 = timed_steps(step3, n2, 3, world, dev)
+        if rank == 0:
+            secondary_skip = {"metric": "rays/sec fwd+bwd (hash-grid model, 64 samples, empty samples skipped)",
+                              "value": world * rays * n2 / dt3, "unit": "rays/s", "n_gpus": world, "steps": n2,
+                              "ms_per_step": 1e3 * dt3 / n2, "dtype": "f32",
+                              "config": {"workload": (NGP_WORKLOAD % rays) + "; samples in empty cells of a synthetic 32^3 occupancy "
+                                                     "grid (a ball filling %.2f of the cube) are dropped before the model: same render as "
+                                                     "zeroing their densities" % (args.occupancy or 0.2),
+                                         "rays_per_gpu": rays, "final_loss": loss3, **info3}}
 
     result = None
     if rank == 0 and args.model == "ngp":
@@ -217,9 +283,12 @@ def gpu_main(args):
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": NGP_WORKLOAD % rays, "rays_per_gpu": rays, "parallelism": "ray-sharded dp%d" % world,
+            "config": {"workload": (NGP_WORKLOAD % rays) + ("; samples in empty cells of a synthetic occupancy grid (a ball filling "
+                                                                "%.2f of the cube) skipped" % args.occupancy if args.occupancy else ""),
+                       "rays_per_gpu": rays, "parallelism": "ray-sharded dp%d" % world,
                        "final_loss": final_loss, **graph_info},
             "roofline": ngp_roofline(model, min(rays, 65536), dev),
+            "dist": who,
         }
     elif rank == 0:
         roof = kernel_roofline(model, min(rays, RAYS_SINGLE) if chunk is None else min(rays, chunk), dev)
@@ -244,9 +313,12 @@ def gpu_main(args):
                        "rays_per_gpu": rays, "parallelism": "ray-sharded dp%d" % world,
                        "final_loss": final_loss},
             "roofline": roof,
+            "dist": who,
         }
         if secondary is not None:
             result["secondary"] = secondary
+        if secondary_skip is not None:
+            result["secondary_skip_empty"] = secondary_skip
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(args.cpu_rays)
     if world > 1:
@@ -254,6 +326,19 @@ def gpu_main(args):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+MLP_SOURCES = ("common.h", "mlp_common.h", "mlp_shared.hip", "mlp_vanilla.hip")
+
+
+def mlp_source_sha():
+    """sha256 over the sources of the three vanilla-MLP kernels: what a set of hardware-counter passes belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in MLP_SOURCES:
+        with open(os.path.join(ROOT, "nerf_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def _time_kernel(fn, iters=5):
@@ -305,11 +390,13 @@ def kernel_roofline(model, rays, dev):
     peak_mfma = PEAK_F16_MATRIX_TFLOPS / MFMA_PER_PRODUCT
     # HBM bytes per launch of that kernel from the committed PMC passes (measured
     # offline with rocprofv3 --pmc: a counter run cannot be nested inside this one)
-    traffic, busy = None, {}
+    # (they belong to one state of the kernel sources: passes collected from other sources are not reported)
+    traffic, busy, stale = None, {}, None
     try:
         with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as fh:
             tr = json.load(fh)
-        if tr.get("points_per_launch") == P and name in tr:
+        stale = tr.get("source_sha256") != mlp_source_sha()
+        if not stale and tr.get("points_per_launch") == P and name in tr:
             traffic = tr[name]["hbm_bytes"]
             busy = {k: tr[k]["mfma_busy"] for k in kernels if k in tr and "mfma_busy" in tr[k]}
     except (OSError, ValueError, KeyError):
@@ -331,7 +418,7 @@ def kernel_roofline(model, rays, dev):
             "note_six": "until the middle of round 2 a product was six bf16 MFMAs (roofline 416.7 fp32-equivalent TFLOP/s, kernels at "
                         "0.49-0.54 of it); halving the MFMAs per product halves the executed-MFMA fraction of the same time, so "
                         "the fp32-equivalent rate against that earlier roofline is given for comparison",
-            "mfma_busy_pmc": busy or None,
+            "mfma_busy_pmc": busy or None, "traffic_stale": stale,
             "note_busy": "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD of the committed rocprofv3 counter pass "
                          "(profiles/roofline_traffic.json): the share of the kernel's own clocks (1.6-2.0 GHz under this load, not "
                          "the 2.4 GHz of the peak) during which the matrix pipe was busy",
@@ -422,7 +509,7 @@ def cpu_baseline(rays, rays_single=128):
         torch.set_num_threads(threads)
     return {"value": all_threads, "unit": "rays/s", "cores": threads, "kind": "port",
             "single_thread": {"value": one_thread, "unit": "rays/s", "cores": 1, "sample": "%d-ray batch" % rays_single},
-            "cpu": _cpu_model_name(), "host_cpus": os.cpu_count(), "torch": torch.__version__,
+            "cpu": _cpu_model_name(), "host_cpus": os.cpu_count(), "torch": torch.__version__, "rays": rays,
             "sample": "%d-ray batch of the same workload (64c+128f, two 8x256 MLPs in 2048-point chunks, fwd+bwd+Adam), "
                       "median of 3 steps after 1 warm-up" % rays}
 
@@ -437,8 +524,11 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the hash-grid result that rides along as 'secondary'")
     ap.add_argument("--model", choices=["vanilla", "ngp"], default="vanilla",
                     help="vanilla = the headline workload; ngp = the hash-grid variant (secondary line)")
-    ap.add_argument("--cpu-rays", type=int, default=1024, help="ray sample of the CPU baseline")
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="ray batch of the CPU baseline's all-thread leg (the batch the metric is quoted on)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--occupancy", type=float, default=None,
+                    help="hash-grid model: skip the samples in empty cells of a synthetic occupancy grid whose occupied cells (a "
+                         "ball) are this fraction of the cube; rides along as 'secondary_skip_empty' at 0.2 by default")
     ap.add_argument("--no-graph", action="store_true",
                     help="issue the hash-grid step launch by launch instead of replaying it from a HIP graph (one GPU, one ray "
                          "chunk): 0.83 against 0.74 ms per 4096-ray step -- at 23 launches per step the host is part of it")

@@ -165,6 +165,29 @@ int nerf_render_loss_bwd(const float* rgb, const float* rgb_fine, const float* t
 int nerf_occupancy_mask(const float* pts, const float* values, int64_t P, const uint8_t* grid,
                         int64_t grid_cells, int grid_res, float* out, void* stream);
 
+/* Skipping the samples nerf_occupancy_mask would zero ("eventually skipping", the step after
+ * src/train_nerf_ngp.py:113-117 and src/utils/analyze_capture_results.py:283-287, which run the model on
+ * every sample and zero the densities of the empty cells afterwards): a sample with sigma = 0 has
+ * weight 0, adds nothing to the colour and receives no gradient, so evaluating the model on the
+ * occupied samples only renders the same image.
+ * nerf_occupancy_compact: stream compaction of pts [P,3] in their own order.  kept [P] (first
+ * *count entries valid): indices of the samples in occupied cells; slot [P]: a sample's position in
+ * that list, -1 if dropped; pts_kept [P,3] / dirs_kept [P,3] (optional): the kept samples'
+ * coordinates and their rays' view directions (dirs has one row per dirs_div consecutive samples);
+ * count: one device int32.  workspace: nerf_occupancy_compact_workspace_ints(P) int32.  Cell lookup
+ * exactly as nerf_occupancy_mask.  P < 2^31.
+ * nerf_expand_kept: rgb [P,3], sigma [P] = the kept samples' model outputs at their places, zeros
+ * at the dropped ones.  nerf_gather_kept: its backward (d_rgb / d_sigma may be null = zeros). */
+size_t nerf_occupancy_compact_workspace_ints(int64_t P);
+int nerf_occupancy_compact(const float* pts, int64_t P, const uint8_t* grid, int64_t grid_cells,
+                           int grid_res, const float* dirs, int dirs_div, int32_t* workspace,
+                           int32_t* kept, int32_t* slot, float* pts_kept, float* dirs_kept,
+                           int32_t* count, void* stream);
+int nerf_expand_kept(const float* rgb_kept, const float* sigma_kept, const int32_t* slot, int64_t P,
+                     float* rgb, float* sigma, void* stream);
+int nerf_gather_kept(const float* d_rgb, const float* d_sigma, const int32_t* kept, int64_t K,
+                     float* d_rgb_kept, float* d_sigma_kept, void* stream);
+
 /* ---------------------------------------------------------- fused MLPs ---- */
 
 /* Vanilla 8x256 NeRF MLP: NeRF.forward (src/models/NeRF.py:67-109) and

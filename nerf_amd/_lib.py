@@ -35,6 +35,10 @@ SIGNATURES = {
     "nerf_composite_fwd": (_I, [_P, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P]),
     "nerf_composite_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _P]),
     "nerf_occupancy_mask": (_I, [_P, _P, _L, _P, _L, _I, _P, _P]),
+    "nerf_occupancy_compact_workspace_ints": (C.c_size_t, [_L]),
+    "nerf_occupancy_compact": (_I, [_P, _L, _P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_expand_kept": (_I, [_P, _P, _P, _L, _P, _P, _P]),
+    "nerf_gather_kept": (_I, [_P, _P, _P, _L, _P, _P, _P]),
     "nerf_mlp_vanilla_pack_floats": (C.c_size_t, []),
     "nerf_mlp_vanilla_pack": (_I, [_P, _I, _P, _P]),
     "nerf_mlp_vanilla_ws_floats_per_point": (C.c_size_t, []),

@@ -240,11 +240,8 @@ __global__ __launch_bounds__(CMP_WAVES * 64) void composite_bwd_kernel(
 // flat index x + 32 y + 1024 z (the reference's xyz_to_idx keeps its default res = 32 whatever the
 // grid resolution is), value kept where grid[index] == 1 and zeroed elsewhere.  An index outside
 // the grid, an IndexError in the reference, is clamped to the nearest stored cell.
-__global__ __launch_bounds__(256) void occupancy_mask_kernel(const float* __restrict__ pts, const float* __restrict__ in,
-                                                             int64_t P, const uint8_t* __restrict__ grid, int64_t cells,
-                                                             float cell, float* __restrict__ out) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
+__device__ __forceinline__ bool cell_occupied(const float* __restrict__ pts, int64_t p, const uint8_t* __restrict__ grid,
+                                              int64_t cells, float cell) {
     long long c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -253,7 +250,114 @@ __global__ __launch_bounds__(256) void occupancy_mask_kernel(const float* __rest
     }
     long long idx = c[0] + c[1] * 32 + c[2] * 1024;
     idx = idx < 0 ? 0 : idx >= cells ? cells - 1 : idx;
-    out[p] = grid[idx] == 1 ? in[p] : 0.0f;
+    return grid[idx] == 1;
+}
+
+__global__ __launch_bounds__(256) void occupancy_mask_kernel(const float* __restrict__ pts, const float* __restrict__ in,
+                                                             int64_t P, const uint8_t* __restrict__ grid, int64_t cells,
+                                                             float cell, float* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    out[p] = cell_occupied(pts, p, grid, cells, cell) ? in[p] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// Skipping the samples the mask would zero.  A masked sample has sigma = 0, hence alpha = 0 and weight 0: it adds
+// nothing to the colour and receives no gradient (src/train_nerf_ngp.py:113-117 zeroes it AFTER the model has
+// run on it).  Dropping it BEFORE the model gives the same render for a fraction of the work.  Stream compaction in
+// the points' own order (so the result does not depend on scheduling): pass 1 counts the kept points of every
+// 1024-point block (wave ballots), pass 2 gives block b the offset sum(counts[0..b)) and writes, for every kept point,
+// its index, its coordinates and its ray's view direction to consecutive slots; `slot` maps a point back to its
+// compact position (-1: dropped).
+// ---------------------------------------------------------------------------
+constexpr int OCC_BLOCK = 1024;
+
+__global__ __launch_bounds__(OCC_BLOCK) void occupancy_count_kernel(const float* __restrict__ pts, int64_t P,
+                                                                    const uint8_t* __restrict__ grid, int64_t cells,
+                                                                    float cell, int32_t* __restrict__ block_counts) {
+    __shared__ int s_wave[OCC_BLOCK / 64];
+    const int64_t p = (int64_t)blockIdx.x * OCC_BLOCK + threadIdx.x;
+    const bool keep = p < P && cell_occupied(pts, p, grid, cells, cell);
+    const int n = __popcll(__ballot(keep));
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < OCC_BLOCK / 64; ++w) total += s_wave[w];
+        block_counts[blockIdx.x] = total;
+    }
+}
+
+__global__ __launch_bounds__(OCC_BLOCK) void occupancy_compact_kernel(
+    const float* __restrict__ pts, int64_t P, const uint8_t* __restrict__ grid, int64_t cells, float cell,
+    const float* __restrict__ dirs, int dirs_div, const int32_t* __restrict__ block_counts, int32_t* __restrict__ kept,
+    int32_t* __restrict__ slot, float* __restrict__ pts_kept, float* __restrict__ dirs_kept, int32_t* __restrict__ count) {
+    __shared__ int s_wave[OCC_BLOCK / 64];
+    __shared__ int s_part[OCC_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this block's offset: the kept points of all earlier blocks
+    int before = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += OCC_BLOCK) before += block_counts[b];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+    if (lane == 0) s_part[wave] = before;
+    const int64_t p = (int64_t)blockIdx.x * OCC_BLOCK + tid;
+    const bool keep = p < P && cell_occupied(pts, p, grid, cells, cell);
+    const unsigned long long votes = __ballot(keep);
+    if (lane == 0) s_wave[wave] = __popcll(votes);
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < OCC_BLOCK / 64; ++w) {
+        base += s_part[w];
+        if (w < wave) base += s_wave[w];
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == OCC_BLOCK - 1) {   // the last thread of all: its prefix + its wave = the total
+        int total = base + s_wave[wave];
+        *count = total;
+    }
+    if (p >= P) return;
+    if (!keep) {
+        slot[p] = -1;
+        return;
+    }
+    const int k = base + __popcll(votes & ((1ull << lane) - 1ull));
+    slot[p] = k;
+    kept[k] = (int32_t)p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pts_kept[3 * (int64_t)k + c] = pts[3 * p + c];
+    if (dirs_kept) {
+        const int64_t r = p / dirs_div;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dirs_kept[3 * (int64_t)k + c] = dirs[3 * r + c];
+    }
+}
+
+// Model outputs of the kept points back at their samples' places, zeros elsewhere (a dropped sample's density is
+// zero as under the mask; its colour, which the mask leaves as the model computed it, is multiplied by a zero
+// weight either way).
+__global__ __launch_bounds__(256) void expand_kept_kernel(const float* __restrict__ rgb_k, const float* __restrict__ sigma_k,
+                                                          const int32_t* __restrict__ slot, int64_t P,
+                                                          float* __restrict__ rgb, float* __restrict__ sigma) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int k = slot[p];
+    sigma[p] = k >= 0 ? sigma_k[k] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[3 * p + c] = k >= 0 ? rgb_k[3 * (int64_t)k + c] : 0.0f;
+}
+
+// The backward of expand_kept: the gradients of the kept samples, in compact order.
+__global__ __launch_bounds__(256) void gather_kept_kernel(const float* __restrict__ d_rgb, const float* __restrict__ d_sigma,
+                                                          const int32_t* __restrict__ kept, int64_t K,
+                                                          float* __restrict__ d_rgb_k, float* __restrict__ d_sigma_k) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int64_t p = kept[k];
+    d_sigma_k[k] = d_sigma ? d_sigma[p] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d_rgb_k[3 * k + c] = d_rgb ? d_rgb[3 * p + c] : 0.0f;
 }
 
 
@@ -417,6 +521,51 @@ extern "C" int nerf_occupancy_mask(const float* pts, const float* values, int64_
     hipLaunchKernelGGL(occupancy_mask_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, pts,
                        values, P, grid, grid_cells, cell, out);
     return check_launch("nerf_occupancy_mask");
+}
+
+extern "C" size_t nerf_occupancy_compact_workspace_ints(int64_t P) { return P > 0 ? (size_t)ceil_div(P, OCC_BLOCK) : 0; }
+
+extern "C" int nerf_occupancy_compact(const float* pts, int64_t P, const uint8_t* grid, int64_t grid_cells, int grid_res,
+                                      const float* dirs, int dirs_div, int32_t* workspace, int32_t* kept, int32_t* slot,
+                                      float* pts_kept, float* dirs_kept, int32_t* count, void* stream) {
+    NERF_REQUIRE(count, "nerf_occupancy_compact: null count");
+    if (P == 0) {
+        if (hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
+            return fail(NERF_ELAUNCH, "nerf_occupancy_compact: cannot clear the count");
+        return NERF_OK;
+    }
+    NERF_REQUIRE(pts && grid && workspace && kept && slot && pts_kept, "nerf_occupancy_compact: null pointer");
+    NERF_REQUIRE(P > 0 && P < (1ll << 31) && grid_cells >= 1 && grid_res >= 1, "nerf_occupancy_compact: P=%lld cells=%lld res=%d",
+                 (long long)P, (long long)grid_cells, grid_res);
+    NERF_REQUIRE(!dirs_kept || (dirs && dirs_div >= 1), "nerf_occupancy_compact: dirs_kept needs dirs and dirs_div >= 1");
+    const float cell = (float)(1.0 / (double)grid_res);
+    const unsigned blocks = (unsigned)ceil_div(P, OCC_BLOCK);
+    hipLaunchKernelGGL(occupancy_count_kernel, dim3(blocks), dim3(OCC_BLOCK), 0, (hipStream_t)stream, pts, P, grid, grid_cells,
+                       cell, workspace);
+    if (int rc = check_launch("nerf_occupancy_compact(count)")) return rc;
+    hipLaunchKernelGGL(occupancy_compact_kernel, dim3(blocks), dim3(OCC_BLOCK), 0, (hipStream_t)stream, pts, P, grid, grid_cells,
+                       cell, dirs, dirs_div, workspace, kept, slot, pts_kept, dirs_kept, count);
+    return check_launch("nerf_occupancy_compact");
+}
+
+extern "C" int nerf_expand_kept(const float* rgb_kept, const float* sigma_kept, const int32_t* slot, int64_t P, float* rgb,
+                                float* sigma, void* stream) {
+    if (P == 0) return NERF_OK;
+    NERF_REQUIRE(slot && rgb && sigma, "nerf_expand_kept: null pointer");
+    NERF_REQUIRE(P > 0, "nerf_expand_kept: P=%lld", (long long)P);
+    hipLaunchKernelGGL(expand_kept_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, rgb_kept,
+                       sigma_kept, slot, P, rgb, sigma);
+    return check_launch("nerf_expand_kept");
+}
+
+extern "C" int nerf_gather_kept(const float* d_rgb, const float* d_sigma, const int32_t* kept, int64_t K, float* d_rgb_kept,
+                                float* d_sigma_kept, void* stream) {
+    if (K == 0) return NERF_OK;
+    NERF_REQUIRE(kept && d_rgb_kept && d_sigma_kept, "nerf_gather_kept: null pointer");
+    NERF_REQUIRE(K > 0, "nerf_gather_kept: K=%lld", (long long)K);
+    hipLaunchKernelGGL(gather_kept_kernel, dim3((unsigned)ceil_div(K, 256)), dim3(256), 0, (hipStream_t)stream, d_rgb, d_sigma,
+                       kept, K, d_rgb_kept, d_sigma_kept);
+    return check_launch("nerf_gather_kept");
 }
 
 extern "C" size_t nerf_render_loss_workspace_floats(int64_t R) { return R > 0 ? 3 * (size_t)loss_blocks(R) : 0; }

@@ -265,6 +265,71 @@ def occupancy_mask(sigma, pts, grid, grid_res: int):
     return _OccupancyMask.apply(sigma, pts, grid, int(grid_res))
 
 
+def occupancy_compact(pts, grid, grid_res: int, dirs=None, dirs_div: int = 1):
+    """The samples of ``pts`` [P,3] that lie in occupied cells of the uint8 ``grid``, in their own order:
+    returns ``(kept int32 [K], slot int32 [P], pts_kept [K,3], dirs_kept [K,3] | None)`` -- ``kept`` the indices,
+    ``slot[p]`` the position of sample p among them or -1, ``dirs_kept`` the rows of ``dirs`` (one per ``dirs_div``
+    consecutive samples) the kept samples belong to.  K is read back from the GPU (one small device-to-host copy:
+    a step that skips samples has data-dependent sizes and cannot be captured into a HIP graph)."""
+    L.need_gpu(pts, grid, dirs)
+    pc = L.f32c(pts.detach()).reshape(-1, 3)
+    if grid.dtype != torch.uint8:
+        raise L.NerfHipError("the occupancy grid must be uint8")
+    gc = grid.contiguous()
+    dc = L.f32c(dirs.detach()) if dirs is not None else None
+    P, dev = pc.shape[0], pc.device
+    lib = L.lib()
+    work = torch.empty(lib.nerf_occupancy_compact_workspace_ints(P), device=dev, dtype=torch.int32)
+    kept = torch.empty(P, device=dev, dtype=torch.int32)
+    slot = torch.empty(P, device=dev, dtype=torch.int32)
+    pts_k = torch.empty(P, 3, device=dev)
+    dirs_k = torch.empty(P, 3, device=dev) if dc is not None else None
+    count = torch.empty(1, device=dev, dtype=torch.int32)
+    if dc is not None:
+        assert dc.shape == ((P + dirs_div - 1) // dirs_div, 3), "dirs must hold one row per dirs_div samples"
+    L.check(lib.nerf_occupancy_compact(L.ptr(pc), P, L.ptr(gc), gc.numel(), int(grid_res), L.ptr(dc), int(dirs_div),
+                                       L.ptr(work), L.ptr(kept), L.ptr(slot), L.ptr(pts_k), L.ptr(dirs_k), L.ptr(count),
+                                       L.stream_of(pc)), "nerf_occupancy_compact")
+    K = int(count.item())
+    return kept[:K], slot, pts_k[:K], (dirs_k[:K] if dirs_k is not None else None)
+
+
+class _ExpandKept(torch.autograd.Function):
+    """(rgb_kept [K,3], sigma_kept [K]) -> (rgb [P,3], sigma [P]): the kept samples' values at their places, zeros at the
+    dropped ones; backward gathers the kept samples' gradients."""
+
+    @staticmethod
+    def forward(ctx, rgb_k, sigma_k, kept, slot):
+        L.need_gpu(rgb_k, sigma_k, kept, slot)
+        rc, sc = L.f32c(rgb_k.detach()).reshape(-1, 3), L.f32c(sigma_k.detach()).reshape(-1)
+        P, K = slot.shape[0], kept.shape[0]
+        assert rc.shape[0] == K and sc.shape[0] == K, "one model output per kept sample"
+        rgb = torch.empty(P, 3, device=slot.device)
+        sigma = torch.empty(P, device=slot.device)
+        L.check(L.lib().nerf_expand_kept(L.ptr(rc), L.ptr(sc), L.ptr(slot), P, L.ptr(rgb), L.ptr(sigma), L.stream_of(slot)),
+                "nerf_expand_kept")
+        ctx.save_for_backward(kept)
+        ctx.shapes = (rgb_k.shape, sigma_k.shape)
+        ctx.set_materialize_grads(False)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        (kept,) = ctx.saved_tensors
+        K = kept.shape[0]
+        d_rgb = L.f32c(d_rgb) if d_rgb is not None else None
+        d_sigma = L.f32c(d_sigma) if d_sigma is not None else None
+        g_rgb = torch.empty(K, 3, device=kept.device)
+        g_sigma = torch.empty(K, device=kept.device)
+        L.check(L.lib().nerf_gather_kept(L.ptr(d_rgb), L.ptr(d_sigma), L.ptr(kept), K, L.ptr(g_rgb), L.ptr(g_sigma),
+                                         L.stream_of(kept)), "nerf_gather_kept")
+        return g_rgb.view(ctx.shapes[0]), g_sigma.view(ctx.shapes[1]), None, None
+
+
+def expand_kept(rgb_kept, sigma_kept, kept, slot):
+    return _ExpandKept.apply(rgb_kept, sigma_kept, kept, slot)
+
+
 class _RenderLoss(torch.autograd.Function):
     """loss = mse(rgb, target) [+ mse(rgb_fine, target)] [+ reg * mean |1 - weights.sum(-1)|] in two launches,
     its gradient in one (src/train_nerf_llff.py:116, src/train_nerf_ngp.py:221-222)."""

@@ -31,6 +31,19 @@ def _eval_model(model, pts, view_dirs, n_per_ray):
     return rgb.view(R, N, 3), sigma.reshape(R, N)
 
 
+def _eval_model_occupied(model, pts, view_dirs, density_grid, grid_res):
+    """``_eval_model`` on the samples in occupied cells only; the others get sigma = 0 (what the mask gives them) and
+    rgb = 0 (their weight is 0 either way)."""
+    R, N = pts.shape[0], pts.shape[1]
+    kept, slot, pts_k, dirs_k = ops.occupancy_compact(pts, density_grid, grid_res, view_dirs, N)
+    if hasattr(model, "_params") and hasattr(model, "_skip_h_first"):
+        rgb_k, sigma_k = ops.vanilla_mlp(pts_k, dirs_k, model._params(), model._skip_h_first)
+    else:
+        rgb_k, sigma_k = model(pts_k, dirs_k)
+    rgb, sigma = ops.expand_kept(rgb_k, sigma_k, kept, slot)
+    return rgb.view(R, N, 3), sigma.view(R, N)
+
+
 def _linspace(near: float, far: float, n: int, dev) -> torch.Tensor:
     """torch.linspace(near, far, n) exactly as the reference's CPU call computes it (src/Camera.py:130): the
     GPU kernel of linspace rounds differently in places, and the depths are held to bit equality."""
@@ -41,7 +54,7 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
                 t_rand: Optional[torch.Tensor] = None, white_bkgd: bool = False, fine_model=None,
                 n_importance: int = 0, u_fine: Optional[torch.Tensor] = None, ndc=None,
                 density_grid: Optional[torch.Tensor] = None, grid_res: Optional[int] = None,
-                z_lin: Optional[torch.Tensor] = None, samples=None):
+                z_lin: Optional[torch.Tensor] = None, samples=None, skip_empty: bool = False):
     """Render a batch of rays [R,3].
 
     Returns a dict with ``rgb`` [R,3], ``weights`` [R,N], ``z_vals`` [R,N],
@@ -56,7 +69,10 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
     normalised world-space directions, and the compositor keeps ``Camera.volume_render``'s convention
     of distances in depth units (not scaled by the length of the NDC direction).
     ``density_grid`` (uint8, from ``get_density_grid``) zeroes the densities of samples in empty cells
-    before compositing, as the hash-grid training render does (src/train_nerf_ngp.py:113-117).
+    before compositing, as the hash-grid training render does (src/train_nerf_ngp.py:113-117).  With
+    ``skip_empty`` those samples are dropped BEFORE the model instead (it runs on the occupied ones only): the same
+    colours, weights and depths -- a sample with zero density has zero weight and no gradient -- for a fraction of the
+    work; the sizes become data-dependent, so such a step cannot be captured into a HIP graph.
     ``samples = (z_vals [R,N], pts [R,N,3])`` supplies coarse samples already drawn (by the fused
     ``ops.raygen_sample``), in which case ``t_rand`` / ``perturb`` / ``z_lin`` are not used.
     """
@@ -75,18 +91,25 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
         if perturb and t_rand is None:
             t_rand = torch.rand(R, n_samples, device=dev)
         z, pts = ops.stratified_sample(rays_o, rays_d, z_lin, t_rand if perturb else None)
-    rgb, sigma = _eval_model(model, pts, view_dirs, n_samples)
-    if density_grid is not None:
-        sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
+    skip = skip_empty and density_grid is not None
+    if skip:
+        rgb, sigma = _eval_model_occupied(model, pts, view_dirs, density_grid, grid_res)
+    else:
+        rgb, sigma = _eval_model(model, pts, view_dirs, n_samples)
+        if density_grid is not None:
+            sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
     c_map, w, depth = ops.composite(rgb, sigma, z, white_bkgd)
     out = {"rgb": c_map, "weights": w, "z_vals": z, "depth": depth}
     if fine_model is not None and n_importance > 0:
         if u_fine is None:
             u_fine = torch.rand(R, n_importance, device=dev)
         _, _, z_all, pts_f = ops.pdf_sample(rays_o, rays_d, z, w, u_fine, want_fine=False)
-        rgb_f, sigma_f = _eval_model(fine_model, pts_f, view_dirs, n_samples + n_importance)
-        if density_grid is not None:
-            sigma_f = ops.occupancy_mask(sigma_f, pts_f, density_grid, grid_res)
+        if skip:
+            rgb_f, sigma_f = _eval_model_occupied(fine_model, pts_f, view_dirs, density_grid, grid_res)
+        else:
+            rgb_f, sigma_f = _eval_model(fine_model, pts_f, view_dirs, n_samples + n_importance)
+            if density_grid is not None:
+                sigma_f = ops.occupancy_mask(sigma_f, pts_f, density_grid, grid_res)
         f_map, w_f, depth_f = ops.composite(rgb_f, sigma_f, z_all, white_bkgd)
         out.update({"rgb_fine": f_map, "weights_fine": w_f, "z_fine": z_all, "depth_fine": depth_f})
     return out
@@ -176,15 +199,16 @@ def get_density_grid(model, device, grid_res: int):
 
 def render_image(model, rays_o, rays_d, near: float, far: float, n_samples: int = 64, grid_res: Optional[int] = None,
                  density_grid: Optional[torch.Tensor] = None, white_bkgd: bool = False, fine_model=None,
-                 n_importance: int = 0, rays_per_tile: int = 65536, return_depth: bool = False, ndc=None):
+                 n_importance: int = 0, rays_per_tile: int = 65536, return_depth: bool = False, ndc=None,
+                 skip_empty: bool = False):
     """Full-image inference: rays [H,W,3] -> colour map [H,W,3] (and depth [H,W]).
 
     The counterpart of ``render_from_model`` (src/utils/analyze_capture_results.py:250-296): unperturbed
     samples, no autograd, sigma zeroed outside the occupancy grid when one is given.  The reference
     materialises all H*W*N points and loops over 16384-point chunks of them; here the loop is over tiles
     of rays and each tile runs sample -> model -> composite end to end.  With ``fine_model`` a second,
-    importance-sampled pass follows (deterministic: evenly spaced CDF positions).  ``ndc`` as in
-    ``render_rays``.
+    importance-sampled pass follows (deterministic: evenly spaced CDF positions).  ``ndc`` and ``skip_empty`` as
+    in ``render_rays``.
     """
     H, W = rays_o.shape[0], rays_o.shape[1]
     o_all, d_all = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
@@ -200,16 +224,23 @@ def render_image(model, rays_o, rays_d, near: float, far: float, n_samples: int 
             if ndc is not None:
                 o, d = ops.ndc_rays(int(ndc[0]), int(ndc[1]), float(ndc[2]), float(ndc[3]), o, d)
             z, pts = ops.stratified_sample(o, d, z_lin, None)
-            rgb, sigma = _eval_model(model, pts, view_dirs, n_samples)
-            if density_grid is not None:
-                sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
+            skip = skip_empty and density_grid is not None
+            if skip:
+                rgb, sigma = _eval_model_occupied(model, pts, view_dirs, density_grid, grid_res)
+            else:
+                rgb, sigma = _eval_model(model, pts, view_dirs, n_samples)
+                if density_grid is not None:
+                    sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
             c_map, w, dep = ops.composite(rgb, sigma, z, white_bkgd)
             if fine_model is not None and n_importance > 0:
                 u = torch.linspace(0.0, 1.0, n_importance, device=dev).expand(o.shape[0], n_importance).contiguous()
                 _, _, z, pts = ops.pdf_sample(o, d, z, w, u, want_fine=False)
-                rgb, sigma = _eval_model(fine_model, pts, view_dirs, n_samples + n_importance)
-                if density_grid is not None:
-                    sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
+                if skip:
+                    rgb, sigma = _eval_model_occupied(fine_model, pts, view_dirs, density_grid, grid_res)
+                else:
+                    rgb, sigma = _eval_model(fine_model, pts, view_dirs, n_samples + n_importance)
+                    if density_grid is not None:
+                        sigma = ops.occupancy_mask(sigma, pts, density_grid, grid_res)
                 c_map, w, dep = ops.composite(rgb, sigma, z, white_bkgd)
             out[r0:r0 + rays_per_tile] = c_map
             if return_depth:
@@ -243,19 +274,12 @@ def psnr(x, y):
 
 
 def nerf_loss(out: dict, target: torch.Tensor) -> torch.Tensor:
-    """MSE of the coarse colour (src/train_nerf_llff.py:116) plus, when a fine
-    pass was rendered, the MSE of the fine colour.  On the GPU one fused op (``ops.render_loss``)."""
-    if out["rgb"].is_cuda and out["rgb"].dtype == torch.float32 and out["rgb"].dim() == 2 and out["rgb"].shape[0] > 0:
-        return ops.render_loss(out["rgb"], target, out.get("rgb_fine"))
-    loss = torch.nn.functional.mse_loss(out["rgb"], target)
-    if "rgb_fine" in out:
-        loss = loss + torch.nn.functional.mse_loss(out["rgb_fine"], target)
-    return loss
+    """MSE of the coarse colour (src/train_nerf_llff.py:116) plus, when a fine pass was rendered, the MSE of the fine
+    colour: one fused op (``ops.render_loss``; GPU tensors only, like every op of this package)."""
+    return ops.render_loss(out["rgb"], target, out.get("rgb_fine"))
 
 
 def ngp_loss(out: dict, target: torch.Tensor, reg: float = 0.05) -> torch.Tensor:
     """The hash-grid loop's loss (src/train_nerf_ngp.py:221-222): MSE plus ``reg`` times the mean deviation of
-    the rays' summed compositing weights from 1.  On the GPU one fused op (``ops.render_loss``)."""
-    if out["rgb"].is_cuda and out["rgb"].dtype == torch.float32 and out["rgb"].dim() == 2 and out["rgb"].shape[0] > 0:
-        return ops.render_loss(out["rgb"], target, weights=out["weights"], reg=reg)
-    return torch.nn.functional.mse_loss(out["rgb"], target) + reg * (1.0 - out["weights"].sum(dim=-1)).abs().mean()
+    the rays' summed compositing weights from 1, as one fused op (``ops.render_loss``)."""
+    return ops.render_loss(out["rgb"], target, weights=out["weights"], reg=reg)

@@ -5,7 +5,11 @@ kernel, whose grid does not depend on the size, the dispatches within 10 % of th
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import mlp_source_sha  # noqa: E402  (the sources the passes were collected from: bench.py checks it)
 
 out_dir = sys.argv[1]
 KERNELS = ("wgrad_kernel", "vanilla_fwd_kernel", "vanilla_bwd_data_kernel")
@@ -42,7 +46,7 @@ res = {"_comment": "HBM bytes per launch at the fine-pass size (786,432 points =
                    "prescribes for 16-byte-per-lane streaming reads on gfx950. mfma_busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / "
                    "(GRBM_GUI_ACTIVE / 8 XCDs) of the same launches: the share of the kernel's clocks during which a SIMD's "
                    "matrix pipe was busy.",
-       "round": 2, "points_per_launch": 786432}
+       "round": 3, "points_per_launch": 786432, "source_sha256": mlp_source_sha()}
 for k in KERNELS:
     f, nf = fine_mean("fetch", k)
     w, _ = fine_mean("write", k)
