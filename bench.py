@@ -77,11 +77,10 @@ NGP_WORKLOAD = ("Instant-NGP variant (16 levels, 2^19 rows, 64-wide MLPs), 800x8
                 "HIP graph and replayed)")
 
 
-def ball_grid(fraction, dev, res=32):
+def ball_grid(radius, dev, res=32):
     """uint8 occupancy grid [res^3] (indexed x + 32 y + 1024 z like the reference's xyz_to_idx): the cells whose centre
-    lies in the ball around the origin that fills `fraction` of the cube [-1, 1]^3 -- a synthetic stand-in for the grid
-    get_density_grid derives from a trained model (src/utils/analyze_capture_results.py:233-248)."""
-    radius = (fraction * 8.0 * 3.0 / (4.0 * math.pi)) ** (1.0 / 3.0)
+    lies in a ball around the origin -- a synthetic stand-in for the grid get_density_grid derives from a trained model
+    (src/utils/analyze_capture_results.py:233-248).  Returns (grid, fraction of the cells that are occupied)."""
     c = (torch.arange(res).float() + 0.5) / res * 2 - 1
     x, y, z = torch.meshgrid(c, c, c, indexing="ij")
     occ = (x ** 2 + y ** 2 + z ** 2) < radius ** 2
@@ -89,6 +88,20 @@ def ball_grid(fraction, dev, res=32):
     grid = torch.zeros(res ** 3, dtype=torch.uint8)
     grid[(ix + iy * 32 + iz * 1024).reshape(-1)] = occ.reshape(-1).to(torch.uint8)
     return grid.to(dev), float(occ.float().mean())
+
+
+def grid_keeping(fraction, pts, dev):
+    """The ball grid that keeps about `fraction` of the samples `pts` (bisection on the radius, at set-up)."""
+    from nerf_amd import ops
+    lo, hi = 0.0, 2.0
+    for _ in range(14):
+        mid = 0.5 * (lo + hi)
+        grid, _ = ball_grid(mid, dev)
+        kept = ops.occupancy_compact(pts, grid, 32)[0].numel() / float(pts.shape[0] * pts.shape[1])
+        lo, hi = (mid, hi) if kept < fraction else (lo, mid)
+    grid, cells = ball_grid(hi, dev)
+    kept = ops.occupancy_compact(pts, grid, 32)[0].numel() / float(pts.shape[0] * pts.shape[1])
+    return grid, {"grid_cells_occupied": cells, "samples_kept": kept, "ball_radius": hi}
 
 
 def build_step(kind, rank, rays, dev, chunk_rays, capturable=False, occupancy=None):
@@ -116,7 +129,8 @@ def build_step(kind, rank, rays, dev, chunk_rays, capturable=False, occupancy=No
         kw = dict(loss_fn=ngp_loss, white_bkgd=False)
         near, far = NGP_NEAR, NGP_FAR
         if occupancy:
-            grid, cells = ball_grid(occupancy, dev)
+            pts0 = ops.raygen_sample(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix, z_lin, u_c)[3]
+            grid, occ_info = grid_keeping(occupancy, pts0, dev)
             kw.update(density_grid=grid, grid_res=32, skip_empty=True)
     else:
         from nerf_amd.models.NeRF import NeRF
@@ -140,8 +154,7 @@ def build_step(kind, rank, rays, dev, chunk_rays, capturable=False, occupancy=No
     step.opt = opt
     step.buckets = buckets
     if kind == "ngp" and occupancy:
-        o, d, z, pts = ops.raygen_sample(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix, z_lin, u_c)
-        step.occupancy = {"grid_cells_occupied": cells, "samples_kept": ops.occupancy_compact(pts, grid, 32)[0].numel() / float(pts.shape[0] * pts.shape[1])}
+        step.occupancy = occ_info
     return step, model
 
 
@@ -172,8 +185,9 @@ def dist_info(world, backend, dev, buckets):
 def build_ngp_step(rank, rays, dev, chunk_rays, world, use_graph, occupancy=None):
     """The hash-grid step; with use_graph captured into a HIP graph and replayed where that applies: one GPU (no
     collective inside the step) and one ray chunk.  Returns (step, model, info for the result's config).
-    occupancy: fraction of an occupancy grid's cells that are occupied (a ball); the step then skips the samples in
-    empty cells (sizes depend on the data: issued launch by launch, never from a graph)."""
+    occupancy: the step skips the samples in empty cells of a synthetic occupancy grid (a ball of occupied cells, sized
+    so that about this fraction of the batch's samples is kept); sizes then depend on the data: the step is issued launch
+    by launch, never from a graph."""
     if occupancy:
         step, model = build_step("ngp", rank, rays, dev, chunk_rays, occupancy=occupancy)
         return step, model, {"hip_graph": False, "skip_empty": True, **step.occupancy}
@@ -272,8 +286,8 @@ def gpu_main(args):
                               "value": world * rays * n2 / dt3, "unit": "rays/s", "n_gpus": world, "steps": n2,
                               "ms_per_step": 1e3 * dt3 / n2, "dtype": "f32",
                               "config": {"workload": (NGP_WORKLOAD % rays) + "; samples in empty cells of a synthetic 32^3 occupancy "
-                                                     "grid (a ball filling %.2f of the cube) are dropped before the model: same render as "
-                                                     "zeroing their densities" % (args.occupancy or 0.2),
+                                                     "grid (a ball of occupied cells keeping %.2f of the samples) are dropped before the model: "
+                                                     "same render as zeroing their densities" % (args.occupancy or 0.2),
                                          "rays_per_gpu": rays, "final_loss": loss3, **info3}}
 
     result = None
@@ -283,8 +297,8 @@ def gpu_main(args):
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (NGP_WORKLOAD % rays) + ("; samples in empty cells of a synthetic occupancy grid (a ball filling "
-                                                                "%.2f of the cube) skipped" % args.occupancy if args.occupancy else ""),
+            "config": {"workload": (NGP_WORKLOAD % rays) + ("; samples in empty cells of a synthetic occupancy grid (a ball of "
+                                                                "occupied cells keeping %.2f of the samples) skipped" % args.occupancy if args.occupancy else ""),
                        "rays_per_gpu": rays, "parallelism": "ray-sharded dp%d" % world,
                        "final_loss": final_loss, **graph_info},
             "roofline": ngp_roofline(model, min(rays, 65536), dev),
@@ -527,8 +541,8 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=4096, help="ray batch of the CPU baseline's all-thread leg (the batch the metric is quoted on)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--occupancy", type=float, default=None,
-                    help="hash-grid model: skip the samples in empty cells of a synthetic occupancy grid whose occupied cells (a "
-                         "ball) are this fraction of the cube; rides along as 'secondary_skip_empty' at 0.2 by default")
+                    help="hash-grid model: skip the samples in empty cells of a synthetic occupancy grid (a ball of occupied cells) "
+                         "that keeps about this fraction of the samples; rides along as 'secondary_skip_empty' at 0.2 by default")
     ap.add_argument("--no-graph", action="store_true",
                     help="issue the hash-grid step launch by launch instead of replaying it from a HIP graph (one GPU, one ray "
                          "chunk): 0.83 against 0.74 ms per 4096-ray step -- at 23 launches per step the host is part of it")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 2
+#define NERF_ABI_VERSION 3
 #define NERF_OK 0
 #define NERF_EINVAL (-22) /* bad argument (shape, null pointer, unsupported size) */
 #define NERF_ELAUNCH (-5) /* the HIP runtime rejected a launch                    */
@@ -330,6 +330,28 @@ int nerf_clip_grad_norm(int count, float* const* grads, const int64_t* numel, fl
  * Same results as nerf_clip_grad_norm, bit for bit. */
 int nerf_clip_grad_norm_static(int count, float* const* grads, const int64_t* numel, float max_norm,
                                float* total_norm, void* stream);
+
+/* The gradient exchange of ray-sharded data-parallel training (no counterpart in the reference,
+ * which is single-process: rays are independent, every rank renders its own batch with replicated
+ * parameters and the only exchange of a step is the sum of the parameter gradients; the same
+ * partitioning nerf_amd/dist.py implements over torch.distributed).
+ * nerf_allreduce_sum: buf[0..n) <- sum over the ranks of rccl_comm (an ncclComm_t), in place, float32,
+ * enqueued on `stream`; one call per gradient bucket (flat buffer) per step, issued as soon as the
+ * kernels filling the bucket are enqueued on that stream.  The communicator may come from the caller's
+ * own RCCL calls or from nerf_comm_init_rank: rank 0 fills a NERF_COMM_ID_BYTES buffer with
+ * nerf_comm_unique_id, hands it to the other ranks by any means, and every rank (one process per
+ * GPU, its device current) calls nerf_comm_init_rank(id, world, rank, &comm); nerf_comm_destroy
+ * ends it.  librccl is resolved at first use -- the copy already loaded into the process (PyTorch
+ * ships one) or else librccl.so.1 -- so the library has no link-time dependency on it; a
+ * communicator must be used with the RCCL copy that created it, which holds when both sides go
+ * through these entry points or through the process's one loaded librccl.
+ * nerf_rccl_version: RCCL's version code (e.g. 22606), -1 if RCCL is unavailable. */
+#define NERF_COMM_ID_BYTES 128
+int nerf_rccl_version(void);
+int nerf_comm_unique_id(void* id128);
+int nerf_comm_init_rank(const void* id128, int world, int rank, void** comm);
+int nerf_comm_destroy(void* comm);
+int nerf_allreduce_sum(float* buf, size_t n, void* rccl_comm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,11 @@ SIGNATURES = {
     "nerf_clip_grad_norm_workspace_floats": (C.c_size_t, [_I, _P]),
     "nerf_clip_grad_norm": (_I, [_I, _P, _P, _F, _P, _P, _P]),
     "nerf_clip_grad_norm_static": (_I, [_I, _P, _P, _F, _P, _P]),
+    "nerf_rccl_version": (_I, []),
+    "nerf_comm_unique_id": (_I, [_P]),
+    "nerf_comm_init_rank": (_I, [_P, _I, _I, _P]),
+    "nerf_comm_destroy": (_I, [_P]),
+    "nerf_allreduce_sum": (_I, [_P, C.c_size_t, _P, _P]),
 }
 
 _lib = None

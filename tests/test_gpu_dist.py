@@ -96,3 +96,31 @@ def test_hash_grid_step_sends_the_tables_before_the_weight_gradients(dev):
             assert err <= 2e-5 * float(r.double().norm()) + 1e-12, (n, err)
     finally:
         dist.destroy_process_group()
+
+
+def test_c_abi_allreduce_with_one_rank(dev):
+    """nerf_allreduce_sum over a communicator made by nerf_comm_unique_id / nerf_comm_init_rank (world 1: the sum is
+    the identity), enqueued behind a kernel of ours on the same stream; a second call reuses the communicator."""
+    import ctypes as C
+    from nerf_amd import _lib as L
+    lib = L.lib()
+    assert lib.nerf_rccl_version() >= 20000
+    ident = (C.c_char * 128)()
+    L.check(lib.nerf_comm_unique_id(ident), "nerf_comm_unique_id")
+    comm = C.c_void_p()
+    torch.cuda.set_device(dev)
+    L.check(lib.nerf_comm_init_rank(ident, 1, 0, C.byref(comm)), "nerf_comm_init_rank")
+    try:
+        assert comm.value
+        gen = torch.Generator().manual_seed(8)
+        for n in (1, 1000, 10_435_874 + 7059):           # up to the hash-grid model's whole gradient
+            buf = torch.randn(n, generator=gen).to(dev)
+            want = buf * 2.0
+            buf.mul_(2.0)                                 # a kernel on the stream in front of the collective
+            L.check(lib.nerf_allreduce_sum(L.ptr(buf), n, comm, L.stream_of(buf)), "nerf_allreduce_sum")
+            torch.cuda.synchronize()
+            assert torch.equal(buf, want)
+        L.check(lib.nerf_allreduce_sum(None, 0, comm, L.stream_of(buf)), "nerf_allreduce_sum")   # empty bucket
+        assert lib.nerf_allreduce_sum(None, 5, comm, L.stream_of(buf)) != 0
+    finally:
+        L.check(lib.nerf_comm_destroy(comm), "nerf_comm_destroy")
