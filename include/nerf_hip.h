@@ -87,6 +87,10 @@ int nerf_pdf_sample(const float* rays_o, const float* rays_d, const float* z, co
 int nerf_ndc_rays(const float* rays_o, const float* rays_d, int64_t R, int H, int W, float focal,
                   float near_, float* out_o, float* out_d, void* stream);
 
+/* view_dirs [R,3] = rays_d / ||rays_d||, the directions the reference's render helpers hand to the model
+ * (src/train_nerf_llff.py:42, src/train_nerf_skow.py:77, src/train_nerf_ngp.py:92). */
+int nerf_normalize_dirs(const float* rays_d, int64_t R, float* out, void* stream);
+
 /* ------------------------------------------------------------ encoders ---- */
 
 /* PositionalEncoding.forward, src/utils/positional_encoding.py:21-36 with

@@ -28,6 +28,7 @@ SIGNATURES = {
     "nerf_raygen_sample": (_I, [_P, _F, _F, _F, _F, _I, _I, _P, _L, _P, _P, _I, _P, _P, _P, _P, _P]),
     "nerf_pdf_sample": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "nerf_ndc_rays": (_I, [_P, _P, _L, _I, _I, _F, _F, _P, _P, _P]),
+    "nerf_normalize_dirs": (_I, [_P, _L, _P, _P]),
     "nerf_encode_pe": (_I, [_P, _L, _I, _I, _P, _P]),
     "nerf_hashgrid_fwd": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P]),
     "nerf_hashgrid_bwd_workspace_bytes": (C.c_size_t, [_L, _P, _I]),

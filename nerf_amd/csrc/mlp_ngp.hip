@@ -16,6 +16,7 @@
 #include "mlp_common.h"
 
 namespace nerf {
+
 namespace np {  // float offsets into the packed buffer
 constexpr int F_D1 = 0;                     // 32 -> 64   (KT 1, OT 2)
 constexpr int F_D2 = F_D1 + 1 * 16 * 64 * 2;  // 64 -> 16(32)  (KT 2, OT 1)
@@ -352,13 +353,13 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
         parts.part[n++] = p;
     }
     {
-        WgradPart p = wgrad_part_desc(DYC, 64, RAW, 32, grads[4], 42, -1, 16, grads[5], 5, DE, 32, 15, 27); // fc_color.0
+        // fc_color.0, and skip_proj with it: hc = W_c1 [feat | pe(dir)] + W_skip feat, so the gradient of W_skip is the
+        // feature columns of the gradient of W_c1 -- the same sums, added to both
+        WgradPart p = wgrad_part_desc(DYC, 64, RAW, 32, grads[4], 42, -1, 16, grads[5], 5, DE, 32, 15, 27);
         p.k_first = 1;
-        parts.part[n++] = p;
-    }
-    {
-        WgradPart p = wgrad_part_desc(DYC, 64, RAW, 32, grads[8], 15, -1, 16, nullptr, 3);                  // skip_proj
-        p.k_first = 1;
+        p.dW2 = grads[8];
+        p.ldW2 = 15;
+        p.col_off2nd = -1;
         parts.part[n++] = p;
     }
     parts.n = n;

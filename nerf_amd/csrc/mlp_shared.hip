@@ -209,7 +209,7 @@ __device__ __forceinline__ void wgrad_mfma(const float (&a)[NTW], const float (&
 // Adds a wave's accumulator tiles (and bias sums) to the gradient tensors.
 // dW[n0 + 32nt + rowmap(r,s)][col + i]: per register two 128-byte row segments
 // scale, scale2: factors applied to the accumulators of the X and X2 blocks on their way out.
-template <int NTW, int KT, int KT2>
+template <int NTW, int KT, int KT2, bool ALIAS = false>
 __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[NTW][KT + KT2], float (&bsum)[NTW], int n0,
                                              int i, int s, bool with_bias = true, float scale = 1.0f, float scale2 = 1.0f) {
     constexpr int KTT = KT + KT2;
@@ -226,6 +226,7 @@ __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[
                     float v = acc[nt][kt][r];
                     asm volatile("" : "+v"(v)::"memory");   // one product at a time: hoisted above the atomics they all spill
                     if (n < pt.n_valid) atomicAdd(pt.dW + (size_t)n * pt.ldW + col, v * (kt < KT ? scale : scale2));
+                    if (ALIAS && pt.dW2 && kt < KT && n < pt.n_valid) atomicAdd(pt.dW2 + (size_t)n * pt.ldW2 + pt.col_off2nd + k, v * scale);
                 }
             }
         }
@@ -238,7 +239,7 @@ __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[
     }
 }
 
-template <int NTW, int KT, int KT2, int NW = 4>
+template <int NTW, int KT, int KT2, int NW = 4, bool ALIAS = false>
 __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
                                            float* lds) {
     using S = WgradShape<NTW, KT, KT2, NW>;
@@ -312,7 +313,7 @@ __device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begi
         });
         cur ^= 1;
     }
-    wgrad_finish<NTW, KT, KT2>(pt, acc, bsum, n0, i, s);
+    wgrad_finish<NTW, KT, KT2, ALIAS>(pt, acc, bsum, n0, i, s);
 }
 
 // ---- The same product on split-f16 MFMAs, the operands split once per workgroup ---------------------
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(WgradParts parts) {
     switch (pt.shape) {
         case 3: wgrad_part<1, 1, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
         case 4: wgrad_part<1, 2, 0, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        default: wgrad_part<1, 1, 1, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
+        default: wgrad_part<1, 1, 1, 2, true>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;   // may feed a second gradient (dW2)
     }
 }
 

@@ -384,9 +384,28 @@ __global__ void ndc_kernel(const float* __restrict__ rays_o, const float* __rest
     out_d[3 * r + 2] = -2.0f * near_ / o[2];
 }
 
+// view_dirs = rays_d / ||rays_d|| (what the reference's render helpers feed the model, src/train_nerf_llff.py:42,
+// src/train_nerf_ngp.py:92): one launch instead of a reduction and a division.
+__global__ void normalize_kernel(const float* __restrict__ d, int64_t R, float* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float x = d[3 * r], y = d[3 * r + 1], z = d[3 * r + 2];
+    const float n = sqrtf((x * x + y * y) + z * z);
+    out[3 * r] = x / n;
+    out[3 * r + 1] = y / n;
+    out[3 * r + 2] = z / n;
+}
+
 }  // namespace nerf
 
 using namespace nerf;
+
+extern "C" int nerf_normalize_dirs(const float* rays_d, int64_t R, float* out, void* stream) {
+    if (R == 0) return NERF_OK;
+    NERF_REQUIRE(rays_d && out && R > 0, "nerf_normalize_dirs: null pointer or R=%lld", (long long)R);
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, rays_d, R, out);
+    return check_launch("nerf_normalize_dirs");
+}
 
 extern "C" int nerf_raygen(const float* c2w, float fx, float fy, float cx, float cy, int H, int W,
                            const int32_t* pix, int64_t R, float* rays_o, float* rays_d, void* stream) {

@@ -114,6 +114,15 @@ def ndc_rays(H: int, W: int, focal: float, near: float, rays_o, rays_d):
     return oo.view(rays_o.shape), dd.view(rays_d.shape)
 
 
+def normalize_dirs(rays_d):
+    """rays_d / ||rays_d|| over the last axis, as one launch."""
+    L.need_gpu(rays_d)
+    d = L.f32c(rays_d.detach()).reshape(-1, 3)
+    out = torch.empty_like(d)
+    L.check(L.lib().nerf_normalize_dirs(L.ptr(d), d.shape[0], L.ptr(out), L.stream_of(d)), "nerf_normalize_dirs")
+    return out.view(rays_d.shape)
+
+
 # ------------------------------------------------------------ encoders ----
 def encode_pe(x: torch.Tensor, num_freqs: int) -> torch.Tensor:
     """[..., D] -> [..., D*(2L+1)].  The encoder input carries no gradient in the

@@ -78,7 +78,7 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
     """
     R = rays_o.shape[0]
     dev = rays_o.device
-    view_dirs = rays_d / rays_d.norm(dim=-1, keepdim=True)   # as render_image does (src/train_nerf_llff.py:42)
+    view_dirs = ops.normalize_dirs(rays_d)   # rays_d / ||rays_d||, as render_image does (src/train_nerf_llff.py:42)
     if ndc is not None:
         H, W, focal, near_plane = ndc
         rays_o, rays_d = ops.ndc_rays(int(H), int(W), float(focal), float(near_plane), rays_o, rays_d)
@@ -220,7 +220,7 @@ def render_image(model, rays_o, rays_d, near: float, far: float, n_samples: int 
     with torch.no_grad():
         for r0 in range(0, R, rays_per_tile):
             o, d = o_all[r0:r0 + rays_per_tile], d_all[r0:r0 + rays_per_tile]
-            view_dirs = d / d.norm(dim=-1, keepdim=True)
+            view_dirs = ops.normalize_dirs(d)
             if ndc is not None:
                 o, d = ops.ndc_rays(int(ndc[0]), int(ndc[1]), float(ndc[2]), float(ndc[3]), o, d)
             z, pts = ops.stratified_sample(o, d, z_lin, None)

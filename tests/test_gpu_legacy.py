@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from conftest import T, load_golden
+from oracle import nerf_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -51,3 +52,44 @@ def test_legacy_volume_render_tail_differs_from_camera(dev):
     a = L.volume_render(rgb, sig, z)
     b, _ = Camera.volume_render(rgb, sig, z)
     assert float((a - b).abs().max()) > 0.1
+
+
+def test_preload_llff_writes_the_three_splits(dev, tmp_path):
+    """src/data/preload_llff_data.py: poses_bounds.npy + images/ -> train/val/test .pt files with the older
+    helpers' rays ([W,H,3], +z forward), the images and per-pixel bounds.  Ten frames: 8 / 1 / 1."""
+    import numpy as np
+    from PIL import Image
+    from nerf_amd.data.preload_llff_data import load_llff_data, precompute_and_split_llff, split_dataset_indices
+    rng = np.random.default_rng(0)
+    N, H, W = 10, 6, 8
+    table = np.zeros((N, 17))
+    for i in range(N):
+        ang = 0.2 * i
+        pose = np.array([[np.cos(ang), 0, np.sin(ang), 0.1 * i], [0, 1, 0, 0.2], [-np.sin(ang), 0, np.cos(ang), 1.0]])
+        table[i, :15] = np.concatenate([pose, np.array([[H], [W], [11.0 + i]])], axis=1).reshape(-1)
+        table[i, 15:] = [1.0 + i, 9.0 + i]
+    (tmp_path / "images").mkdir()
+    np.save(tmp_path / "poses_bounds.npy", table)
+    imgs = rng.integers(0, 256, size=(N, H, W, 3), dtype=np.uint8)
+    for i in range(N):
+        Image.fromarray(imgs[i]).save(tmp_path / "images" / ("%03d.png" % i))
+    poses, bounds, images = load_llff_data(str(tmp_path))
+    assert poses.shape == (N, 3, 5) and bounds.shape == (N, 2) and len(images) == N
+    assert torch.equal(images[3], torch.from_numpy(imgs[3].astype(np.float32) / 255.0))
+    np.random.seed(5)
+    want_split = split_dataset_indices(N)
+    assert [len(s) for s in want_split] == [8, 1, 1] and sorted(sum(want_split, [])) == list(range(N))
+    np.random.seed(5)
+    precompute_and_split_llff(str(tmp_path), str(tmp_path / "parts"), H=H, W=W, device=dev)
+    for name, idx in zip(("train", "val", "test"), want_split):
+        part = torch.load(tmp_path / "parts" / (name + ".pt"), weights_only=False)
+        assert part["rays_o"].shape == (len(idx), W, H, 3) and part["near"].shape == (len(idx), H, W)
+        assert float(part["focal"]) == 11.0
+        for k, i in enumerate(idx):
+            c2w = torch.eye(4)
+            c2w[:3, :4] = torch.from_numpy(poses[i][:, :4])
+            o, d = O.legacy_get_rays(H, W, float(poses[i, -1, -1]), c2w)
+            assert torch.equal(part["rays_o"][k], o.contiguous())
+            assert float((part["rays_d"][k] - d).abs().max()) < 1e-6
+            assert torch.equal(part["rgb"][k], images[i])
+            assert float(part["near"][k][0, 0]) == bounds[i, 0] and float(part["far"][k][-1, -1]) == bounds[i, 1]
