@@ -626,6 +626,7 @@ int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     const long long tiles = P32 / 32;
     // narrow: at least 64 tiles (2048 points) per slab -- every workgroup ends in atomics on the same few lines of
     // the gradients -- and at most 2048 workgroups
+    // (measured at 262,144 points: 64 tiles per slab 0.709 ms per step, 32: 0.712, 16: 0.759, 8: 0.775)
     const long long narrow_blocks = parts.n * tiles / 64;
     const int target_blocks = !narrow ? 512 : (int)(narrow_blocks < 256 ? 256 : narrow_blocks > 2048 ? 2048 : narrow_blocks);
     int used = 0;
