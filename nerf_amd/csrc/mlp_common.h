@@ -141,9 +141,14 @@ template <int NT>
 __device__ __forceinline__ void save_tiles(const TileBuf& tb, float* __restrict__ rows0, int ld, const f32x16 (&a)[NT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        // The tile may be the destination of MFMAs issued just before: a 32 x 32 MFMA delivers its result up to 18
+        // cycles after it issues, the compiler spaces only the readers it knows, and the readers here are asm.  (Seen
+        // as a saved matrix that held partial sums while the registers, read later, were right.)
+        f32x16 v16 = a[t];
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(v16));
         static_for<0, 4>([&](auto cq) {
             constexpr int q = decltype(cq)::value;
-            lds_write4<32 * q>(tb.wr, f32x4{a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]});
+            lds_write4<32 * q>(tb.wr, f32x4{v16[4 * q], v16[4 * q + 1], v16[4 * q + 2], v16[4 * q + 3]});
         });
         f32x4 v[4];
         static_for<0, 4>([&](auto ck) { v[ck] = lds_read4<8 * decltype(ck)::value * TILE_LD * 4>(tb.rd); });
