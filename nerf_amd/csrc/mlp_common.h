@@ -756,9 +756,6 @@ struct WgradPart {
     const float* sk_d;       // optional rider on a split-f16 part: a per-point scalar d[P32] whose product with X is
     float* sk_dW;            // accumulated alongside, sk_dW[k] += sum_p d[p] X[p][k], sk_db[0] += sum_p d[p] (the gradient
     float* sk_db;            // of a one-output head that reads the same X, in plain fp32 on the lanes that load X)
-    float* dW2;        // optional second gradient that receives the X block's columns as well: dW2[n][col_off2nd + k] += the same
-    int ldW2;          // sums (a layer applied to the same input beside this one, e.g. a skip projection of the features)
-    int col_off2nd;
     int shape;         // index into the (NTW, KT, KT2) instantiation list
     int slabs;         // point slabs this part is split into
     int first_block;   // prefix sum of slabs

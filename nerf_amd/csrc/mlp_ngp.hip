@@ -9,11 +9,9 @@
 // levels 8h .. 8h+7 of point p, which fills
 // the 16 registers of the first MFMA's B tile directly: register r of lane half
 // h is feature 16h + r, and the packed first-layer weight is permuted to match.
-// The backward kernel ends in the same layout, so each lane scatters the
-// gradient of exactly the levels it gathered (float atomics into the tables).
+// The backward kernel ends in the same layout: each lane writes the gradient of exactly
+// the levels it read, level-major again, for the table-gradient scatter (encode.hip).
 // Compiled with -ffp-contract=off: the interpolation rounds like the reference.
-#include <cstdlib>
-
 #include "hashgrid.h"
 #include "mlp_common.h"
 
@@ -42,13 +40,11 @@ constexpr int DE = 128;     // [P32][32]
 constexpr int HC = 160;     // [P32][64]
 constexpr int MASK = 224;   // [P32/32][2][64] u32
 constexpr int PER_POINT = 228;
-constexpr int DYC = 0;      // [P32][64]
-constexpr int DRAW = 64;    // [P32][32]
-constexpr int DYD = 96;     // [P32][64]
-constexpr int DOUT4 = 160;  // [P32][4]
-constexpr int DENC = 164;   // [16][P32][2] gradient of the encoding, level-major like the encoding itself
-constexpr int PART = 196;   // the fused backward kernel's partial weight-gradient sums, one slot per workgroup
-constexpr int PER_POINT2 = 196 + 68;
+// backward workspace
+constexpr int DOUT4 = 0;    // [P32][4] = (d sigma_pre, d rgb_pre[3]), for the colour head's gradient
+constexpr int DENC = 4;     // [16][P32][2] gradient of the encoding, level-major like the encoding itself
+constexpr int PART = 36;    // the backward kernel's partial weight-gradient sums: one slot of 8,512 floats per workgroup
+constexpr int PER_POINT2 = PART + 68;   // (a workgroup per 128 points at most: 66.5 floats per point)
 }  // namespace nw
 
 
@@ -206,78 +202,11 @@ __global__ __launch_bounds__(256, 3) void ngp_fwd_kernel(const float* __restrict
     }
 }
 
-// Backward-data chain ending in the hash-table scatter.
-__global__ __launch_bounds__(256, 4) void ngp_bwd_data_kernel(const float* __restrict__ x, const float* __restrict__ d_rgb,
-                                                           const float* __restrict__ d_sigma, long long P,
-                                                           const float* __restrict__ pk,
-                                                           const float* __restrict__ rgb,
-                                                           const float* __restrict__ sigma,
-                                                           const float* __restrict__ ws, float* __restrict__ ws2) {
-    __shared__ __attribute__((aligned(16))) float s_tile[4][TILE_LDS_FLOATS];   // as in the forward kernel
-    NgpIdx ix;
-    if (!ngp_index(P, ix)) return;
-    const int lane = ix.lane, h = ix.h;
-    const TileBuf tb = tile_buf(s_tile[threadIdx.x >> 6], lane);
-    const unsigned* mask = reinterpret_cast<const unsigned*>(ws + ix.P32 * nw::MASK) + ix.tile * 128 + lane;
-    float dpre[3], dps = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float o = rgb[3 * ix.lp + c];
-        dpre[c] = ix.valid ? d_rgb[3 * ix.lp + c] * o * (1.0f - o) : 0.0f;
-    }
-    if (ix.valid) dps = d_sigma[ix.lp] * (1.0f - expf(-sigma[ix.lp]));
-    if (h == 0) *reinterpret_cast<float4*>(ws2 + ix.P32 * nw::DOUT4 + ix.gp * 4) = make_float4(dps, dpre[0], dpre[1], dpre[2]);
-    // d hc = W4^T d rgb_pre, masked
-    f32x16 dyc[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float4 w = *reinterpret_cast<const float4*>(pk + np::S_WC2 + 64 * c + 32 * t + 8 * q + 4 * h);
-                s.x = fmaf(w.x, dpre[c], s.x);
-                s.y = fmaf(w.y, dpre[c], s.y);
-                s.z = fmaf(w.z, dpre[c], s.z);
-                s.w = fmaf(w.w, dpre[c], s.w);
-            }
-            dyc[t][4 * q + 0] = s.x;
-            dyc[t][4 * q + 1] = s.y;
-            dyc[t][4 * q + 2] = s.z;
-            dyc[t][4 * q + 3] = s.w;
-        }
-    apply_bits2(dyc, mask[64]);
-    save_tiles<2>(tb, ws2 + ix.P32 * nw::DYC + ix.tile * (32 * 64), 64, dyc);
-    // d raw: features through (W3 + Wskip)^T, density through softplus'
-    f32x16 draw[1];
-    zero_tiles<1>(draw);
-    dense<2, 1>(pk + np::B_C1, dyc, draw, lane);
-    if (h == 0) draw[0][0] += dps;
-    save_tiles<1>(tb, ws2 + ix.P32 * nw::DRAW + ix.tile * (32 * 32), 32, draw);
-    f32x16 dyd[2];
-    zero_tiles<2>(dyd);
-    dense<1, 2>(pk + np::B_D2, draw, dyd, lane);
-    apply_bits2(dyd, mask[0]);
-    save_tiles<2>(tb, ws2 + ix.P32 * nw::DYD + ix.tile * (32 * 64), 64, dyd);
-    f32x16 de[1];
-    zero_tiles<1>(de);
-    dense<2, 1>(pk + np::B_D1, dyd, de, lane);   // register r = d feature (16h + r): this lane's own levels
-    // The table gradients are scattered by further launches (launch_hashgrid_scatter), which walk the levels one
-    // after the other: level-major, so that each reads a contiguous run.  This lane holds d feature 16h + r in
-    // register r, i.e. levels 8h .. 8h+7; 32 consecutive lanes write 256 contiguous bytes per level.
-    float* denc = ws2 + ix.P32 * nw::DENC;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        *reinterpret_cast<float2*>(denc + 2 * ((8 * h + j) * ix.P32 + ix.gp)) = make_float2(de[0][2 * j], de[0][2 * j + 1]);
-}
-
-
 // ---------------------------------------------------------------------------
-// The same backward-data chain with the weight gradients formed in the same kernel.
-// As separate launches the chain wrote d(pre-activation) of its three layers to memory (0.8 KB per point) for a
-// work list of GEMMs to read back together with the saved inputs: 2.8 KB per point of traffic for 7,059 parameters.
-// Here a wave keeps all of its weight-gradient tiles in registers (8 tiles = 128 accumulators) across the tiles
+// Backward: the backward-data chain (d rgb, d sigma -> d encoding) with the weight gradients formed in the same
+// kernel.  As separate launches the chain wrote d(pre-activation) of its three layers to memory (0.8 KB per point)
+// for a work list of GEMMs to read back together with the saved inputs: 2.8 KB per point of traffic for 7,059
+// parameters (1.12 + 1.07 ms per 4.2 M points; this kernel: 1.16).  Here a wave keeps all of its weight-gradient tiles in registers (8 tiles = 128 accumulators) across the tiles
 // of points it walks, adds them to the gradients once at the end, and nothing but the gradient of the encoding
 // (for the table scatter) and d(sigma_pre, rgb_pre) (for the colour head's 3 x 64 gradient) is written.
 //   dW[n][k] = sum_p dY[p][n] X[p][k] on v_mfma_f32_32x32x2_f32: A = dY^T (row = neuron, contraction = point),
@@ -668,8 +597,9 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
     for (int l = 0; l < 16; ++l) NERF_REQUIRE(d_tables[l], "nerf_mlp_ngp_bwd: gradient table %d is null", l);
     hipStream_t st = (hipStream_t)stream;
     const long long P32 = (P + 31) / 32 * 32;
-    static const bool fused = !(getenv("NERF_NGP_FUSED") && atoi(getenv("NERF_NGP_FUSED")) == 0);
-    if ((phases & 1) && fused) {
+    if (phases & 1) {
+        // The backward-data chain with the weight gradients of the three layers it walks, then the table gradients:
+        // d_tables and all of `grads` but the colour head's are complete when these launches are.
         const NgpGrads g{grads[0], grads[1], grads[2], grads[3], grads[4], grads[5], grads[8]};
         // one slot of partial sums per workgroup, as many workgroups as ws2 has room for slots (2 per CU at most)
         long long wgs = ceil_div(P32 / 32, 4);
@@ -679,49 +609,15 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
         if (partials && wgs > room) wgs = room;
         hipLaunchKernelGGL(ngp_bwd_fused_kernel, dim3((unsigned)wgs), dim3(256), 0, st, d_rgb, d_sigma,
                            (long long)P, packed, rgb, sigma, ws, ws2, g, partials);
-        if (int rc = check_launch("nerf_mlp_ngp_bwd(fused)")) return rc;
+        if (int rc = check_launch("nerf_mlp_ngp_bwd(chain)")) return rc;
         if (partials) {
             static_assert(NGP_PART_FLOATS % RED_E == 0, "whole blocks of elements");
             hipLaunchKernelGGL(ngp_wgrad_reduce_kernel, dim3(NGP_PART_FLOATS / RED_E), dim3(RED_E * RED_G), 0, st, partials, (int)wgs, g);
             if (int rc = check_launch("nerf_mlp_ngp_bwd(reduce)")) return rc;
         }
         if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, P32, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st)) return rc;
-    } else if (phases & 1) {   // the backward-data chain and the table gradients, which are complete when these launches are
-        hipLaunchKernelGGL(ngp_bwd_data_kernel, dim3((unsigned)ceil_div(P, 128)), dim3(256), 0, st, x, d_rgb, d_sigma,
-                           (long long)P, packed, rgb, sigma, ws, ws2);
-        if (int rc = check_launch("nerf_mlp_ngp_bwd(data)")) return rc;
-        if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, P32, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st)) return rc;
     }
     if (!(phases & 2)) return NERF_OK;
-
-    if (fused) {
-        SkinnyPart c2f{ws2 + P32 * nw::DOUT4, ws + P32 * nw::HC, grads[6], grads[7], 4, 64, 1, 3, 64};     // fc_color.2
-        return launch_skinny(c2f, P32, st);
-    }
-    const float *E = ws + P32 * nw::E, *HD = ws + P32 * nw::HD, *RAW = ws + P32 * nw::RAW, *DE = ws + P32 * nw::DE,
-                *HC = ws + P32 * nw::HC;
-    const float *DYC = ws2 + P32 * nw::DYC, *DRAW = ws2 + P32 * nw::DRAW, *DYD = ws2 + P32 * nw::DYD,
-                *DOUT4 = ws2 + P32 * nw::DOUT4;
-    WgradParts parts{};
-    int n = 0;
-    parts.part[n++] = wgrad_part_desc(DYD, 64, E, 32, grads[0], 32, 0, 32, grads[1], 3);                    // fc_density.0
-    {
-        WgradPart p = wgrad_part_desc(DRAW, 32, HD, 64, grads[2], 64, 0, 64, grads[3], 4);                  // fc_density.2
-        p.n_valid = 16;
-        parts.part[n++] = p;
-    }
-    {
-        // fc_color.0, and skip_proj with it: hc = W_c1 [feat | pe(dir)] + W_skip feat, so the gradient of W_skip is the
-        // feature columns of the gradient of W_c1 -- the same sums, added to both
-        WgradPart p = wgrad_part_desc(DYC, 64, RAW, 32, grads[4], 42, -1, 16, grads[5], 5, DE, 32, 15, 27);
-        p.k_first = 1;
-        p.dW2 = grads[8];
-        p.ldW2 = 15;
-        p.col_off2nd = -1;
-        parts.part[n++] = p;
-    }
-    parts.n = n;
-    if (int rc = launch_wgrad(parts, P32, st)) return rc;
-    SkinnyPart c2{DOUT4, HC, grads[6], grads[7], 4, 64, 1, 3, 64};                                           // fc_color.2
+    SkinnyPart c2{ws2 + P32 * nw::DOUT4, ws + P32 * nw::HC, grads[6], grads[7], 4, 64, 1, 3, 64};   // fc_color.2: d(sigma, rgb)_pre x hc
     return launch_skinny(c2, P32, st);
 }

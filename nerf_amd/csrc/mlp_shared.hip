@@ -1,5 +1,5 @@
-// Kernels shared by the fused MLPs: weight packing, the weight-gradient GEMMs
-// (contraction over points on split-f16 or exact-f32 MFMAs) and the small-head gradients.
+// Kernels shared by the fused MLPs: weight packing, the weight-gradient GEMMs of the 8x256 MLP
+// (contraction over points on split-f16 MFMAs) and the small-head gradients.
 #include "mlp_common.h"
 
 namespace nerf {
@@ -88,128 +88,13 @@ int launch_amax_reduce(const unsigned* per_wave, long long tiles, unsigned* out,
 // ---------------------------------------------------------------- wgrad ----
 // One workgroup (4 waves) owns one point slab of one part; wave w owns n-tiles
 // [w*NTW, (w+1)*NTW) and all k-tiles (KT from X plus KT2 from X2), i.e.
-// NTW*(KT+KT2) accumulator tiles (up to 320 registers).
-//
-// The slab is streamed through LDS in chunks of 32 points: the dY, X and X2 rows
-// of a chunk are copied global -> LDS by direct-to-LDS loads (16 B per lane, one
-// whole 1 KiB row segment per wave instruction), two chunk buffers deep, so the
-// loads of chunk c+1 are in flight during all 16 k-steps of chunk c (about 8 us
-// of cover for an HBM miss under load).  MFMA operands are then conflict-free
-// ds_read_b32 (32 consecutive floats per lane half), fetched one k-step ahead.
-constexpr int WG_CH = 32;                          // points per chunk
-constexpr int WG_LDS_FLOATS = 3 * 16 * (3 * 256 + 4);   // three k-steps of 16 split operand tiles (145 KiB); also holds two raw chunks
-
-// NW = waves along the output dimension (N = NW*NTW*32 columns of dY); the other
-// 4/NW wave groups split the k-steps of every chunk between them.
-template <int NTW, int KT, int KT2, int NW = 4>
-struct WgradShape {
-    static constexpr int N = NW * NTW * 32, XW = KT * 32, X2W = KT2 * 32, KTT = KT + KT2, G = 4 / NW;
-    static constexpr int DY_OFF = 0, X_OFF = WG_CH * N, X2_OFF = WG_CH * (N + XW);
-    static constexpr int CHUNK = WG_CH * (N + XW + X2W);   // floats per buffer
-    static_assert(CHUNK % 256 == 0, "a chunk must be a whole number of 1 KiB pieces");
-    static_assert(2 * CHUNK <= WG_LDS_FLOATS, "chunk buffers exceed the LDS allocation");
-};
-
-// Per-lane source pointers of one part for the direct-to-LDS copies, built once from
-// the kernel-argument table (a direct-to-LDS load is an opaque memory write to the
-// compiler: anything still read through the table would be re-fetched, and waited
-// for, after every piece).
-//
-// A chunk buffer is copied in pieces of 1 KiB (one wave instruction, 16 B per lane);
-// the four waves take pieces 4q..4q+3 together.  Every sub-block (dY, X, X2) is a
-// whole number of 4 KiB and every row length divides 1024 floats, so the source of
-// piece group q is known at compile time and a lane's (row, column) within the group
-// never changes: pointer = lane base + (p0 + q * rows per group) * row stride.
-template <int NTW, int KT, int KT2, int NW>
-struct WgradSrc {
-    using S = WgradShape<NTW, KT, KT2, NW>;
-    static constexpr int X2W = S::X2W ? S::X2W : 32;
-    static_assert(1024 % S::N == 0 && 1024 % S::XW == 0 && 1024 % X2W == 0, "row lengths must divide a piece group");
-    static_assert(S::X_OFF % 1024 == 0 && S::X2_OFF % 1024 == 0 && S::CHUNK % 1024 == 0, "sub-blocks must be whole piece groups");
-    static constexpr int GROUPS = S::CHUNK / 1024;   // pieces per wave per chunk
-    const float *dY, *X, *X2;
-    long long ldY, ldX, ldX2;
-    int wave;
-
-    __device__ __forceinline__ WgradSrc(const WgradPart& pt, int wave_, int lane) : wave(wave_) {
-        const int off = 256 * wave_ + 4 * lane;       // float offset of this lane within a piece group
-        ldY = pt.ldY; ldX = pt.ldX; ldX2 = pt.ldX2;
-        dY = pt.dY + (off / S::N) * ldY + off % S::N;
-        X = pt.X + (off / S::XW) * ldX + off % S::XW;
-        X2 = KT2 ? pt.X2 + (off / X2W) * ldX2 + off % X2W : nullptr;
-    }
-
-    // Enqueue piece groups [Q0, Q1) of the chunk that starts at point p0 into buf.
-    template <int Q0, int Q1>
-    __device__ __forceinline__ void stage(long long p0, float* buf) const {
-#pragma unroll
-        for (int q = Q0; q < Q1; ++q) {
-            const float* g;
-            if (q * 1024 < S::X_OFF) {
-                g = dY + (p0 + q * (1024 / S::N)) * ldY;
-            } else if (KT2 == 0 || q * 1024 < S::X2_OFF) {
-                g = X + (p0 + (q - S::X_OFF / 1024) * (1024 / S::XW)) * ldX;
-            } else {
-                g = X2 + (p0 + (q - S::X2_OFF / 1024) * (1024 / X2W)) * ldX2;
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(buf + q * 1024 + wave * 256), 16, 0, 0);
-        }
-    }
-};
-
-// LDS reads of the MFMA operands are issued as asm: the compiler would order them
-// (and the waits for them) by its own cost model, and it makes every LDS read it
-// knows of wait for the direct-to-LDS copies in flight.  The waits are explicit:
-// lds_wait() before the first use of what lds_read() requested.
-template <int OFF_BYTES>
-__device__ __forceinline__ float lds_read(unsigned addr) {
-    float r;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF_BYTES));
-    return r;
-}
-template <int NA, int NB>
-__device__ __forceinline__ void lds_wait(float (&a)[NA], float (&b)[NB]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // the operands pass through an empty asm so that no use of them can move above the wait
-#pragma unroll
-    for (int k = 0; k < NA; ++k) asm volatile("" : "+v"(a[k]));
-#pragma unroll
-    for (int k = 0; k < NB; ++k) asm volatile("" : "+v"(b[k]));
-}
-
-// LDS byte addresses of this lane's operand rows at k-step 0 of a chunk buffer.
-struct WgradRows {
-    unsigned dy, x, x2;
-};
-
-// Request the MFMA operands of the wave's k-step number J (points 2u and 2u+1 of
-// the chunk, u = g + G*J; g is folded into the row addresses).
-template <int NTW, int KT, int KT2, int NW, int J>
-__device__ __forceinline__ void wgrad_fetch(const WgradRows& rows, float (&a)[NTW], float (&b)[KT + KT2]) {
-    using S = WgradShape<NTW, KT, KT2, NW>;
-    constexpr int U = S::G * J;
-    static_for<0, NTW>([&](auto nt) { a[nt] = lds_read<(2 * U * S::N + 32 * decltype(nt)::value) * 4>(rows.dy); });
-    static_for<0, KT>([&](auto kt) { b[kt] = lds_read<(2 * U * S::XW + 32 * decltype(kt)::value) * 4>(rows.x); });
-    static_for<0, KT2>([&](auto kt) { b[KT + kt] = lds_read<(2 * U * S::X2W + 32 * decltype(kt)::value) * 4>(rows.x2); });
-}
-
-// MFMAs [M0, M1) of a k-step, numbered nt * KTT + kt.  Each result passes through an
-// empty asm: an MFMA is a pure operation to the compiler, which would otherwise sink
-// the MFMAs of a whole chunk below all of its LDS reads.
-template <int NTW, int KTT, int M0, int M1>
-__device__ __forceinline__ void wgrad_mfma(const float (&a)[NTW], const float (&b)[KTT], f32x16 (&acc)[NTW][KTT]) {
-#pragma unroll
-    for (int m = M0; m < M1; ++m) {
-        acc[m / KTT][m % KTT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m / KTT], b[m % KTT], acc[m / KTT][m % KTT], 0, 0, 0);
-        asm volatile("" : "+a"(acc[m / KTT][m % KTT]));
-    }
-}
+// NTW*(KT+KT2) accumulator tiles (up to 256 registers).
+constexpr int WG_LDS_FLOATS = 3 * 16 * (3 * 256 + 4);   // three k-steps of 16 split operand tiles (145 KiB)
 
 // Adds a wave's accumulator tiles (and bias sums) to the gradient tensors.
 // dW[n0 + 32nt + rowmap(r,s)][col + i]: per register two 128-byte row segments
 // scale, scale2: factors applied to the accumulators of the X and X2 blocks on their way out.
-template <int NTW, int KT, int KT2, bool ALIAS = false>
+template <int NTW, int KT, int KT2>
 __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[NTW][KT + KT2], float (&bsum)[NTW], int n0,
                                              int i, int s, bool with_bias = true, float scale = 1.0f, float scale2 = 1.0f) {
     constexpr int KTT = KT + KT2;
@@ -226,7 +111,6 @@ __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[
                     float v = acc[nt][kt][r];
                     asm volatile("" : "+v"(v)::"memory");   // one product at a time: hoisted above the atomics they all spill
                     if (n < pt.n_valid) atomicAdd(pt.dW + (size_t)n * pt.ldW + col, v * (kt < KT ? scale : scale2));
-                    if (ALIAS && pt.dW2 && kt < KT && n < pt.n_valid) atomicAdd(pt.dW2 + (size_t)n * pt.ldW2 + pt.col_off2nd + k, v * scale);
                 }
             }
         }
@@ -239,84 +123,7 @@ __device__ __forceinline__ void wgrad_finish(const WgradPart& pt, f32x16 (&acc)[
     }
 }
 
-template <int NTW, int KT, int KT2, int NW = 4, bool ALIAS = false>
-__device__ __forceinline__ void wgrad_part(const WgradPart& pt, long long p_begin, long long p_end, int wave, int lane,
-                                           float* lds) {
-    using S = WgradShape<NTW, KT, KT2, NW>;
-    constexpr int KTT = KT + KT2;
-    constexpr int G = S::G;                       // wave groups sharing the k-steps
-    constexpr int STEPS = WG_CH / 2 / G;          // k-steps per wave per chunk
-    constexpr int M = NTW * KTT;                  // MFMAs per k-step
-    static_assert(STEPS % 2 == 0, "the operand ping-pong needs an even step count");
-    const int i = lane & 31, s = lane >> 5;
-    const int n0 = (wave % NW) * NTW * 32;
-    const int g = wave / NW;
-    f32x16 acc[NTW][KTT];
-    float bsum[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        bsum[nt] = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < KTT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][kt][r] = 0.0f;
-    }
-    const WgradSrc<NTW, KT, KT2, NW> src(pt, wave, lane);
-    constexpr int PW = WgradSrc<NTW, KT, KT2, NW>::GROUPS;
-    src.template stage<0, PW>(p_begin, lds);
-    int cur = 0;
-#pragma unroll 1
-    for (long long p = p_begin; p < p_end; p += WG_CH) {
-        // Every wave's copies of this chunk have landed (the barrier's fence drains the
-        // wave's own direct-to-LDS loads first) and every wave is done with the other buffer.
-        __syncthreads();
-        const bool more = p + WG_CH < p_end;
-        const float* buf = lds + cur * S::CHUNK;
-        float* nxt = lds + (cur ^ 1) * S::CHUNK;
-        const WgradRows rows{lds_addr(buf + S::DY_OFF + (2 * g + s) * S::N + n0 + i),
-                             lds_addr(buf + S::X_OFF + (2 * g + s) * S::XW + i),
-                             lds_addr(buf + S::X2_OFF + (2 * g + s) * S::X2W + i)};
-        float a0[NTW], b0[KTT], a1[NTW], b1[KTT];
-        wgrad_fetch<NTW, KT, KT2, NW, 0>(rows, a0, b0);
-        // Schedule of a k-step: wait for its operands (requested a whole step earlier),
-        // its first MFMA, then the LDS reads of the next step and a share of the next
-        // chunk's copies, then the other MFMAs.  The copies all go out in the first
-        // STAGE_STEPS steps, so that the last of them has the remaining steps to land
-        // before the barrier waits for it.
-        constexpr int STAGE_STEPS = STEPS * 3 / 8 > 0 ? STEPS * 3 / 8 : 1;
-        constexpr int PPS = (PW + STAGE_STEPS - 1) / STAGE_STEPS;
-        constexpr auto q_of = [](int step) { return step * PPS < PW ? step * PPS : PW; };
-        static_for<0, STEPS / 2>([&](auto jj) {   // this wave's k-steps are g, g+G, g+2G, ...
-            constexpr int j = 2 * decltype(jj)::value;
-            lds_wait(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            wgrad_mfma<NTW, KTT, 0, 1>(a0, b0, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            wgrad_fetch<NTW, KT, KT2, NW, j + 1>(rows, a1, b1);
-            if (more) src.template stage<q_of(j), q_of(j + 1)>(p + WG_CH, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            wgrad_mfma<NTW, KTT, 1, M>(a0, b0, acc);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) bsum[nt] += a0[nt];
-            __builtin_amdgcn_sched_barrier(0);
-            lds_wait(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            wgrad_mfma<NTW, KTT, 0, 1>(a1, b1, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j + 2 < STEPS) wgrad_fetch<NTW, KT, KT2, NW, j + 2>(rows, a0, b0);
-            if (more) src.template stage<q_of(j + 1), q_of(j + 2)>(p + WG_CH, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            wgrad_mfma<NTW, KTT, 1, M>(a1, b1, acc);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) bsum[nt] += a1[nt];
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        cur ^= 1;
-    }
-    wgrad_finish<NTW, KT, KT2, ALIAS>(pt, acc, bsum, n0, i, s);
-}
-
-// ---- The same product on split-f16 MFMAs, the operands split once per workgroup ---------------------
+// ---- The product on split-f16 MFMAs, the operands split once per workgroup --------------------------
 // K = 16 points per MFMA: lane (i, hb) holds points 8hb..8hb+7 of column i of dY (A operand) or of X (B operand).
 // If every wave split each X tile it multiplies with, a workgroup would do that work four times.  Here a k-step
 // (16 points) of dY and X is loaded into registers once, split there into two f16 pieces (see dense_h3 in
@@ -561,8 +368,9 @@ __device__ __forceinline__ void wgrad_part_pk(const WgradPart& pt, long long p_b
     }
 }
 
-// shape ids (NTW,KT,KT2,NW): 0 = <2,8,0,4>  1 = <1,8,1,4>  2 = <2,2,0,4>   (a 320-register <2,8,2> tile set does
-// not allocate without spills; the first three on split-f16 MFMAs, the rest on the exact-f32 MFMA);  small layers of the hash-grid model: 3 = <1,1,0,2>  4 = <1,2,0,1>  5 = <1,1,1,2>
+// shape ids (NTW,KT,KT2): 0 = <2,8,0>  1 = <1,8,1>  2 = <2,2,0>, all on split-f16 MFMAs (a 320-register <2,8,2> tile set
+// does not allocate without spills).  The hash-grid model's small layers form their weight gradients inside its
+// backward kernel (mlp_ngp.hip).
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
     int pi = 0;
@@ -581,54 +389,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParts parts) {
             else wgrad_part_pk<2, 8, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds);
             break;
         case 1: wgrad_part_pk<1, 8, 1, 3>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        default: wgrad_part_pk<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;   // 2; the narrow shapes 3-5: wgrad_small_kernel
+        default: wgrad_part_pk<2, 2, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;   // 2
     }
 }
 
-// The narrow shapes of the hash-grid model in a kernel of their own: their two chunk buffers take 32 KiB and their
-// accumulators a few dozen registers, so several workgroups fit a CU -- in wgrad_kernel they inherited its 148 KiB of
-// LDS and 480 registers, i.e. four waves per CU for work that is bound by its reads (1.59 ms for 7 GB).
-constexpr int WG_SMALL_LDS_FLOATS = 2 * WG_CH * (64 + 32 + 32);
-static_assert(2 * WgradShape<1, 1, 0, 2>::CHUNK <= WG_SMALL_LDS_FLOATS && 2 * WgradShape<1, 2, 0, 1>::CHUNK <= WG_SMALL_LDS_FLOATS &&
-                  2 * WgradShape<1, 1, 1, 2>::CHUNK <= WG_SMALL_LDS_FLOATS, "chunk buffers of the narrow shapes");
-__global__ __launch_bounds__(256) void wgrad_small_kernel(WgradParts parts) {
-    __shared__ __attribute__((aligned(16))) float lds[WG_SMALL_LDS_FLOATS];
-    int pi = 0;
-#pragma unroll 1
-    while (pi + 1 < parts.n && (int)blockIdx.x >= parts.part[pi + 1].first_block) ++pi;
-    const WgradPart& pt = parts.part[pi];
-    const int slab = blockIdx.x - pt.first_block;
-    const long long tiles = parts.P32 / 32;
-    const long long t0 = tiles * slab / pt.slabs, t1 = tiles * (slab + 1) / pt.slabs;
-    if (t0 >= t1) return;   // uniform for the whole workgroup
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    switch (pt.shape) {
-        case 3: wgrad_part<1, 1, 0, 2>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        case 4: wgrad_part<1, 2, 0, 1>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;
-        default: wgrad_part<1, 1, 1, 2, true>(pt, t0 * 32, t1 * 32, wave, lane, lds); break;   // may feed a second gradient (dW2)
-    }
-}
-
-// Relative time per point of a workgroup of each shape (the first three from sweeps of the ratios at 786,432
-// points: 3.62 ms with 32:24:17 for :22, 3.21 ms with 24:19:22; the 64-wide shape then moved from a per-wave split to
-// the shared one: 3.16 ms with :17; the narrow shapes run below their MFMA count): the cost model of the slab split.
-static const int kShapeCost[6] = {24, 19, 17, 8, 8, 8};
+// Relative time per point of a workgroup of each shape (from sweeps of the ratios at 786,432 points: 3.62 ms with
+// 32:24:17 for :22, 3.21 ms with 24:19:22; the 64-wide shape then moved from a per-wave split to the shared one:
+// 3.16 ms with :17): the cost model of the slab split.
+static const int kShapeCost[3] = {24, 19, 17};
 
 int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
-    // A list is either the wide split-f16 shapes (a workgroup takes a whole CU: 512 registers per lane, so the grid is
-    // sized to exactly two equal-cost rounds of the 256 CUs, slabs proportional to cost) or the narrow shapes of the
-    // hash-grid model (several workgroups per CU: four rounds' worth of smaller slabs).
-    bool narrow = parts.n > 0 && parts.part[0].shape >= 3;
-    for (int i = 0; i < parts.n; ++i)
-        if ((parts.part[i].shape >= 3) != narrow) return fail(NERF_EINVAL, "wgrad: wide and narrow shapes in one list");
+    // A workgroup takes a whole CU (512 registers per lane), so the grid is sized to exactly two equal-cost rounds of
+    // the 256 CUs, slabs proportional to cost.
     long long total_cost = 0;
-    for (int i = 0; i < parts.n; ++i) total_cost += kShapeCost[parts.part[i].shape];
+    for (int i = 0; i < parts.n; ++i) {
+        if (parts.part[i].shape < 0 || parts.part[i].shape > 2) return fail(NERF_EINVAL, "wgrad: unknown shape %d", parts.part[i].shape);
+        total_cost += kShapeCost[parts.part[i].shape];
+    }
     const long long tiles = P32 / 32;
-    // narrow: at least 64 tiles (2048 points) per slab -- every workgroup ends in atomics on the same few lines of
-    // the gradients -- and at most 2048 workgroups
-    // (measured at 262,144 points: 64 tiles per slab 0.709 ms per step, 32: 0.712, 16: 0.759, 8: 0.775)
-    const long long narrow_blocks = parts.n * tiles / 64;
-    const int target_blocks = !narrow ? 512 : (int)(narrow_blocks < 256 ? 256 : narrow_blocks > 2048 ? 2048 : narrow_blocks);
+    const int target_blocks = 512;
     int used = 0;
     for (int i = 0; i < parts.n; ++i) {
         long long s = target_blocks * (long long)kShapeCost[parts.part[i].shape] / total_cost;
@@ -656,8 +435,7 @@ int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
     }
     parts.total_blocks = first;
     parts.P32 = P32;
-    if (narrow) hipLaunchKernelGGL(wgrad_small_kernel, dim3(first), dim3(256), 0, stream, parts);
-    else hipLaunchKernelGGL(wgrad_kernel, dim3(first), dim3(256), 0, stream, parts);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(first), dim3(256), 0, stream, parts);
     return check_launch("wgrad");
 }
 
