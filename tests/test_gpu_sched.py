@@ -234,3 +234,43 @@ def test_capturable_state_loads_into_per_parameter_step_optimisers(dev):
     for pa, pb, pc, pd in zip(a, b, c, d):
         for q in (pa, pb, pc):
             assert torch.allclose(q, pd, rtol=3e-6, atol=1e-7), float((q.detach() - pd.detach()).abs().max())
+
+
+@pytest.mark.parametrize("which", ["step", "plateau", "exponential"])
+def test_torch_schedulers_drive_fused_adam_like_torch_adam(dev, which):
+    """StepLR(100, 0.5) (src/train_nerf_llff.py:83, src/train_nerf_skow.py:48), ReduceLROnPlateau(mode='max', factor=0.3,
+    patience=4, threshold=0.003, threshold_mode='abs', min_lr=3e-4) (src/train_nerf_ngp.py:57-61) and ExponentialLR over
+    FusedAdam -- eager and capturable -- against the same scheduler over torch.optim.Adam: the same rates, the same
+    parameters."""
+    from nerf_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(17)
+    shapes = [(64, 33), (64,), (4099, 2)]
+    init = [torch.randn(s, generator=gen) for s in shapes]
+    mk = lambda: [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+
+    def sched_of(opt):
+        if which == "step":
+            return torch.optim.lr_scheduler.StepLR(opt, step_size=3, gamma=0.5)
+        if which == "plateau":
+            return torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="max", factor=0.3, patience=1, threshold=0.003,
+                                                              threshold_mode="abs", min_lr=3e-4)
+        return torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+
+    sets = [mk(), mk(), mk()]
+    opts = [torch.optim.Adam(sets[0], lr=1e-2, eps=1e-15), FusedAdam(sets[1], lr=1e-2, eps=1e-15),
+            FusedAdam(sets[2], lr=1e-2, eps=1e-15, capturable=True)]
+    scheds = [sched_of(o) for o in opts]
+    metric = [0.30, 0.31, 0.311, 0.3115, 0.3116, 0.40, 0.401, 0.4011, 0.4012, 0.4012, 0.4012, 0.4012]   # a "validation SSIM"
+    for it in range(12):
+        grads = [(torch.randn(s, generator=gen) * 0.1).to(dev) for s in shapes]
+        for ps, o in zip(sets, opts):
+            for p, gr in zip(ps, grads):
+                p.grad = gr.clone()
+            o.step()
+        for sc in scheds:
+            sc.step(metric[it]) if which == "plateau" else sc.step()
+        lrs = [o.param_groups[0]["lr"] for o in opts]
+        assert lrs[0] == lrs[1] == lrs[2], (it, lrs)
+        for a, b, c in zip(*sets):
+            assert torch.allclose(a, b, rtol=3e-6, atol=1e-7) and torch.allclose(a, c, rtol=3e-6, atol=1e-7), it
+    assert opts[0].param_groups[0]["lr"] < 1e-2      # the schedule did something
