@@ -274,11 +274,12 @@ int nerf_mlp_ngp_fwd(const float* x, const float* dirs, int dirs_div, int64_t P,
  * the parameters' by plain additions of per-workgroup sums in a fixed order): zero them first.
  * ws2: ceil32(P)*ws2_floats_per_point floats of scratch.  scatter_ws / scatter_ws_bytes: the
  * workspace of nerf_hashgrid_bwd (nerf_hashgrid_bwd_workspace_bytes(P, sizes, 16)), or NULL / 0.
- * phases: bit 0 runs the backward kernel -- the backward-data chain with the weight gradients of
- * fc_density.0/.2, fc_color.0 and skip_proj formed in the same pass -- and the table-gradient scatter
- * (d_tables and those gradients are complete when these launches are); bit 1 the gradient of the
- * colour head fc_color.2 (needs the ws2 of bit 0); 3 = both.  A data-parallel caller issues 1, starts the
- * all-reduce of the table gradients (41.7 MB) and issues 2. */
+ * phases: bit 0 runs the backward kernel -- the backward-data chain, which also forms the
+ * weight-gradient sums of fc_density.0/.2, fc_color.0 and skip_proj per workgroup -- and the
+ * table-gradient scatter: d_tables is complete when these launches are.  Bit 1 adds those sums to
+ * `grads` and forms the gradient of the colour head fc_color.2 (needs the ws2 of bit 0, untouched in
+ * between); 3 = both.  A data-parallel caller issues 1, starts the all-reduce of the table gradients
+ * (41.7 MB) and issues 2.  (With fewer than 128 points bit 0 adds to `grads` directly.) */
 int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, int64_t P,
                      const int* res, const int* sizes, const float* packed, const float* rgb,
                      const float* sigma, float* ws, float* ws2, float* const* d_tables,

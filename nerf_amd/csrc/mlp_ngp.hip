@@ -597,27 +597,28 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
     for (int l = 0; l < 16; ++l) NERF_REQUIRE(d_tables[l], "nerf_mlp_ngp_bwd: gradient table %d is null", l);
     hipStream_t st = (hipStream_t)stream;
     const long long P32 = (P + 31) / 32 * 32;
+    // The backward kernel leaves one slot of partial weight-gradient sums per workgroup in ws2: as many workgroups as
+    // there is room for slots (2 per CU at most); with no room at all (a handful of tiles) it adds to `grads` directly.
+    const NgpGrads g{grads[0], grads[1], grads[2], grads[3], grads[4], grads[5], grads[8]};
+    long long wgs = ceil_div(P32 / 32, 4);
+    wgs = wgs < 512 ? wgs : 512;
+    const long long room = P32 * (nw::PER_POINT2 - nw::PART) / NGP_PART_FLOATS;
+    float* partials = room >= 1 ? ws2 + P32 * nw::PART : nullptr;
+    if (partials && wgs > room) wgs = room;
     if (phases & 1) {
-        // The backward-data chain with the weight gradients of the three layers it walks, then the table gradients:
-        // d_tables and all of `grads` but the colour head's are complete when these launches are.
-        const NgpGrads g{grads[0], grads[1], grads[2], grads[3], grads[4], grads[5], grads[8]};
-        // one slot of partial sums per workgroup, as many workgroups as ws2 has room for slots (2 per CU at most)
-        long long wgs = ceil_div(P32 / 32, 4);
-        wgs = wgs < 512 ? wgs : 512;
-        const long long room = P32 * (nw::PER_POINT2 - nw::PART) / NGP_PART_FLOATS;
-        float* partials = room >= 1 ? ws2 + P32 * nw::PART : nullptr;   // a handful of tiles: direct atomics
-        if (partials && wgs > room) wgs = room;
+        // the backward-data chain with the weight-gradient sums of the three layers it walks, then the table gradients:
+        // d_tables is complete when these launches are
         hipLaunchKernelGGL(ngp_bwd_fused_kernel, dim3((unsigned)wgs), dim3(256), 0, st, d_rgb, d_sigma,
                            (long long)P, packed, rgb, sigma, ws, ws2, g, partials);
         if (int rc = check_launch("nerf_mlp_ngp_bwd(chain)")) return rc;
-        if (partials) {
-            static_assert(NGP_PART_FLOATS % RED_E == 0, "whole blocks of elements");
-            hipLaunchKernelGGL(ngp_wgrad_reduce_kernel, dim3(NGP_PART_FLOATS / RED_E), dim3(RED_E * RED_G), 0, st, partials, (int)wgs, g);
-            if (int rc = check_launch("nerf_mlp_ngp_bwd(reduce)")) return rc;
-        }
         if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, P32, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st)) return rc;
     }
     if (!(phases & 2)) return NERF_OK;
+    if (partials) {   // grads += the workgroups' sums, in a fixed order
+        static_assert(NGP_PART_FLOATS % RED_E == 0, "whole blocks of elements");
+        hipLaunchKernelGGL(ngp_wgrad_reduce_kernel, dim3(NGP_PART_FLOATS / RED_E), dim3(RED_E * RED_G), 0, st, partials, (int)wgs, g);
+        if (int rc = check_launch("nerf_mlp_ngp_bwd(reduce)")) return rc;
+    }
     SkinnyPart c2{ws2 + P32 * nw::DOUT4, ws + P32 * nw::HC, grads[6], grads[7], 4, 64, 1, 3, 64};   // fc_color.2: d(sigma, rgb)_pre x hc
     return launch_skinny(c2, P32, st);
 }
