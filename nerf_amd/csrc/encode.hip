@@ -227,7 +227,7 @@ constexpr int BIN_RUN = 8;            // records per 128-byte line
 constexpr int BIN_SLOTS = BIN_REC + BIN_MAX_SEGS * (BIN_RUN - 1);   // a workgroup's records of a level, every run padded
 constexpr int BIN_MIN_SUB = 8;        // queues per segment at least; a reduce workgroup takes at most this many
 constexpr unsigned BIN_NO_DEST = 0xffffffffu;
-constexpr long long BIN_SLICE_RECORDS = 131072;
+constexpr long long BIN_SLICE_RECORDS = 131072, BIN_SLICE_MIN = 32768;   // records per reduce workgroup of a full segment: at most, at least
 struct BinLevels {
     float* table[HG_MAX_LEVELS];
     long long q_off[HG_MAX_LEVELS];     // record offset of the level's queues
@@ -557,7 +557,15 @@ static BinPlan bin_plan(int64_t P, int size) {
     pl.nseg = (int)ceil_div(size, BIN_SEG_ROWS);
     const int64_t seg_rows = size < BIN_SEG_ROWS ? size : BIN_SEG_ROWS;
     const int64_t share = ceil_div(4 * P * seg_rows, (int64_t)size);
-    pl.slices = (int)ceil_div(share, BIN_SLICE_RECORDS);
+    // A reduce workgroup's time is its records' (4 LDS atomics each) plus a fixed zero-and-flush of its image, and the
+    // launch takes as long as its longest workgroup: a slice is about 1/512 of the records of a 14-level batch (two
+    // rounds of the 256 CUs) within [BIN_SLICE_MIN, BIN_SLICE_RECORDS].  (At 262,144 points slices of 131,072 records
+    // left the few-segment levels to 10-14 workgroups that ran three times as long as all the others.)
+    // (swept at 262,144 and 1,048,576 points: P/9 with a floor of 32,768 and P/4 with 65,536 tie; floors of 16,384
+    // and 8,192 lose 1-4 % to the images' zero-and-flush)
+    int64_t slice = P / 9;
+    slice = slice < BIN_SLICE_MIN ? BIN_SLICE_MIN : slice > BIN_SLICE_RECORDS ? BIN_SLICE_RECORDS : slice;
+    pl.slices = (int)ceil_div(share, slice);
     pl.nsub = pl.slices > BIN_MIN_SUB ? pl.slices : BIN_MIN_SUB;
     const int64_t wgs = ceil_div(ceil_div(P, BIN_PTS), pl.nsub);           // bin workgroups per queue
     const int64_t sub_share = ceil_div(share, pl.nsub), pads = (BIN_RUN - 1) * wgs, most = 4 * wgs * BIN_PTS + pads;
