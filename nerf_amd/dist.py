@@ -217,11 +217,25 @@ def accumulate_step(n_items: int, chunk: int, loss_of_chunk: Callable[[int, int]
                 loss = loss * ((hi - lo) / n_items)
             if buckets is not None and k == len(spans) - 1:
                 buckets.arm()
-            (loss * grad_scale if grad_scale != 1.0 else loss).backward()
+            # the root gradient is a constant kept per device: left to autograd it is a ones_like() fill per backward
+            (loss * grad_scale if grad_scale != 1.0 else loss).backward(gradient=_one(loss))
             total = loss.detach() if total is None else total + loss.detach()
     if buckets is not None:
         buckets.finish()
     return total
+
+
+_ONES = {}
+
+
+def _one(like: torch.Tensor) -> torch.Tensor:
+    if like.dim() != 0:
+        return torch.ones_like(like)
+    key = (like.device, like.dtype)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((), device=like.device, dtype=like.dtype)
+    return t
 
 
 class GradAverager:
