@@ -233,6 +233,7 @@ struct BinLevels {
     long long q_off[HG_MAX_LEVELS];     // record offset of the level's queues
     int res[HG_MAX_LEVELS];
     unsigned size[HG_MAX_LEVELS];
+    unsigned magic[HG_MAX_LEVELS];      // mod_magic_of(size)
     int id[HG_MAX_LEVELS];              // position of the level in the encoding
     int nseg[HG_MAX_LEVELS];
     int nsub[HG_MAX_LEVELS];            // queues per segment: a bin workgroup appends to queue (its index % nsub)
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
     __syncthreads();
 #pragma unroll 1
     for (int j = 0; j < lv.n; ++j) {
-        const unsigned size = lv.size[j], cap = lv.cap[j];
+        const unsigned size = lv.size[j], magic = lv.magic[j], cap = lv.cap[j];
         const int nseg = lv.nseg[j], nsub = lv.nsub[j], sub = blockIdx.x % nsub;
         float* __restrict__ tab = lv.table[j];
         reinterpret_cast<float2*>(s_xch)[tid] = g_next;   // requested an iteration ago
@@ -311,7 +312,12 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
         for (int yz = 0; yz < 4; ++yz) {
             const unsigned cy = (yz & 2) ? c.hi[1] : c.lo[1], cz = (yz & 1) ? c.hi[2] : c.lo[2];
             const float wy = (yz & 2) ? c.w[1] : 1.0f - c.w[1], wz = (yz & 1) ? c.w[2] : 1.0f - c.w[2];
-            const unsigned r_lo = hash_row(c.lo[0], cy, cz, size), r_hi = hash_row(c.hi[0], cy, cz, size);
+            // the hash is linear in x: unless x wraps around the grid or the 32-bit sum around zero, the high-x
+            // corner's sum is the low-x one's plus one, and so is its remainder
+            const unsigned h_yz = cy * 2654435761u + cz * 805459861u, h_lo = c.lo[0] + h_yz;
+            const unsigned r_lo = row_of_sum(h_lo, size, magic);
+            unsigned r_hi = r_lo + 1 == size ? 0u : r_lo + 1;
+            if (c.hi[0] != c.lo[0] + 1 || h_lo == 0xffffffffu) r_hi = row_of_sum(c.hi[0] + h_yz, size, magic);
             const float w_lo = ((1.0f - c.w[0]) * wy) * wz, w_hi = (c.w[0] * wy) * wz;
             seg[yz] = r_lo / BIN_SEG_ROWS;
             loc[yz] = r_lo % BIN_SEG_ROWS;
@@ -619,6 +625,7 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
             bl.table[j] = d_tables[l];
             bl.res[j] = res[l];
             bl.size[j] = (unsigned)sizes[l];
+            bl.magic[j] = mod_magic_of((unsigned)sizes[l]);
             bl.id[j] = l;
             bl.nseg[j] = pl.nseg;
             bl.nsub[j] = pl.nsub;

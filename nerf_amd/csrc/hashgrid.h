@@ -45,6 +45,18 @@ __device__ __forceinline__ unsigned hash_row(unsigned cx, unsigned cy, unsigned 
     return (size & (size - 1)) == 0 ? h & (size - 1) : h % size;   // uniform over a level
 }
 
+// h % size for a size that is not a power of two, given magic = floor(2^32 / size): mulhi(h, magic) is the
+// quotient or one less for every 32-bit h (h magic / 2^32 lies in (h / size - 1, h / size]), so one correction
+// completes it -- 6 instructions where the division by a run-time value takes 15, five of them quarter-rate multiplies.
+__host__ __device__ __forceinline__ unsigned mod_magic_of(unsigned size) {
+    return (size & (size - 1)) ? (unsigned)((1ull << 32) / size) : 0u;   // 0: a power of two, masked instead
+}
+__device__ __forceinline__ unsigned row_of_sum(unsigned h, unsigned size, unsigned magic) {
+    if (magic == 0u) return h & (size - 1);   // uniform over a level
+    const unsigned r = h - __umulhi(h, magic) * size;
+    return r >= size ? r - size : r;
+}
+
 struct Cell {
     unsigned lo[3], hi[3];
     float w[3];
