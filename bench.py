@@ -367,6 +367,31 @@ def _time_kernel(fn, iters=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def sustained_mfma_probe():
+    """What the card's matrix cores sustain on real data, measured now: tools/microbench/mfma_sustained (a loop of
+    nothing but 32x32x16 f16 MFMAs on random register operands, every CU, ~80 ms per launch) run as a child process.
+    The nominal 2.5 PFLOP/s is 2.4 GHz; under its power limit the card holds about 1.66 GHz in that loop.  None when
+    the probe has not been built."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "microbench", "mfma_sustained")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=60).stdout
+        rows = [ln.split() for ln in out.splitlines() if ln.startswith("random")]
+        tflops = [float(r[r.index("TFLOP/s") - 1]) for r in rows]
+        mhz = [float(r[r.index("MHz") - 1]) for r in rows]
+        if not tflops:
+            return None
+        return {"f16_tflops": tflops[-1], "shader_clock_mhz": mhz[-1], "frac_of_nominal": tflops[-1] / PEAK_F16_MATRIX_TFLOPS,
+                "launches_tflops": tflops,
+                "what": "v_mfma_f32_32x32x16_f16 back to back on random normal register operands, one wave per SIMD on every "
+                        "CU, no memory traffic, last of 4 launches of ~80 ms (tools/microbench/mfma_sustained.hip); with "
+                        "all-zero operands the same loop runs at 2.39 GHz and 0.99 of nominal"}
+    except (OSError, ValueError, subprocess.SubprocessError):
+        return None
+
+
 def kernel_roofline(model, rays, dev):
     """Time the three MLP kernels alone (HIP events on the launch stream) at the
     fine-pass size and report the one that takes most of the step."""
@@ -419,6 +444,10 @@ def kernel_roofline(model, rays, dev):
     hbm_bound = gbs / PEAK_HBM_GBS >= tflops / peak_mfma
     per_kernel = {k: {"ms": v[0] * 1e3, "tflops": v[1] * P / v[0] / 1e12, "mfma_frac": v[1] * P / v[0] / 1e12 / peak_mfma,
                       "gbs": v[2] * P / v[0] / 1e9, "hbm_frac": v[2] * P / v[0] / 1e9 / PEAK_HBM_GBS} for k, v in kernels.items()}
+    sustained = sustained_mfma_probe()
+    if sustained:
+        for v in per_kernel.values():
+            v["frac_of_sustained_mfma"] = v["tflops"] * MFMA_PER_PRODUCT / sustained["f16_tflops"]
     return {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
             "achieved": gbs if hbm_bound else tflops, "peak": PEAK_HBM_GBS if hbm_bound else peak_mfma,
             "unit": "GB/s" if hbm_bound else "TFLOP/s",
@@ -436,6 +465,11 @@ def kernel_roofline(model, rays, dev):
             "note_busy": "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD of the committed rocprofv3 counter pass "
                          "(profiles/roofline_traffic.json): the share of the kernel's own clocks (1.6-2.0 GHz under this load, not "
                          "the 2.4 GHz of the peak) during which the matrix pipe was busy",
+            "sustained_mfma_measured": sustained,
+            "frac_of_sustained_mfma": tflops * MFMA_PER_PRODUCT / sustained["f16_tflops"] if sustained else None,
+            "note_sustained": "frac and peak above are against the nominal 2.5 PFLOP/s (2.4 GHz); sustained_mfma_measured is what a "
+                              "loop of nothing but f16 MFMAs on random operands reaches on this card in this run (the power limit "
+                              "lowers the clock), and frac_of_sustained_mfma the kernel's executed f16 MFMA rate against that",
             "all_kernels": per_kernel,
             "all_kernels_ms": {k: v[0] * 1e3 for k, v in kernels.items()}}
 
