@@ -269,7 +269,12 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
                                                                const float* __restrict__ d_out, int levels,
                                                                int64_t level_stride, BinLevels lv,
                                                                unsigned* __restrict__ counters, float4* __restrict__ queues) {
-    __shared__ unsigned s_hist[BIN_MAX_SEGS], s_start[BIN_MAX_SEGS + 1], s_gbase[BIN_MAX_SEGS];
+    // The kernel is bound by latency, not by a unit (vector ALU and LDS ~30 % busy each, waves waiting 60 % of their
+    // time): what counts per level is the number of barriers and what the returning atomic that reserves queue space
+    // has to overlap with.  Three barriers per level: B (histogram complete) -- reserve, prefix sums, the records'
+    // values -- C -- records to their sorted places -- D -- copy-out.  The histogram alternates between two arrays so
+    // that the next level's counting needs no barrier behind the copy-out: the other array was cleared between B and C.
+    __shared__ unsigned s_hist[2][BIN_MAX_SEGS], s_start[BIN_MAX_SEGS + 1], s_gbase[BIN_MAX_SEGS];
     __shared__ unsigned s_dest[BIN_SLOTS];
     __shared__ float4 s_rec[BIN_SLOTS];
     const int tid = threadIdx.x;
@@ -278,17 +283,20 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
     // reduce pass would add them to the same row in one instruction, the slowest case of an LDS atomic.  Wave w
     // takes the points w, w + 8, w + 16, ... of each of eight runs of 64: neighbours end up in different waves,
     // whose records enter the queues at different times.
-    // Loads stay coalesced: thread t loads point t and hands it to its owner through the record buffer, which is idle
-    // at that point of the loop.
+    // The coordinates are loaded coalesced (thread t loads point t) and handed to their owners through the record
+    // buffer, idle at that point; the gradient of a level is loaded by the owner itself, a level ahead (8 bytes per
+    // lane at a stride of 64: every line of the workgroup's 4 KiB is touched by all eight waves, which the L1 absorbs).
     static_assert(BIN_PTS == 512, "the mapping below permutes 8 waves x 64 lanes");
     const int pt_in_wg = ((tid & 63) >> 3) * 64 + (tid >> 6) + 8 * (tid & 7);
     const int64_t p = (int64_t)blockIdx.x * BIN_PTS + pt_in_wg;
     const bool valid = p < P;
-    const int64_t p_load = min((int64_t)blockIdx.x * BIN_PTS + tid, P - 1);   // the point this thread loads
+    const int64_t p_own = valid ? p : P - 1;
+    const int64_t p_load = min((int64_t)blockIdx.x * BIN_PTS + tid, P - 1);   // the point whose coordinates this thread loads
     float* s_xch = reinterpret_cast<float*>(s_rec);
 #pragma unroll
     for (int k = 0; k < 3; ++k) s_xch[3 * tid + k] = x[3 * p_load + k];
-    float2 g_next = *reinterpret_cast<const float2*>(d_out + denc_index(p_load, lv.id[0], levels, level_stride));
+    float2 g_next = *reinterpret_cast<const float2*>(d_out + denc_index(p_own, lv.id[0], levels, level_stride));
+    if (tid < 2 * BIN_MAX_SEGS) (&s_hist[0][0])[tid] = 0u;
     __syncthreads();
     const float xyz[3] = {s_xch[3 * pt_in_wg], s_xch[3 * pt_in_wg + 1], s_xch[3 * pt_in_wg + 2]};
     __syncthreads();
@@ -297,48 +305,43 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
         const unsigned size = lv.size[j], magic = lv.magic[j], cap = lv.cap[j];
         const int nseg = lv.nseg[j], nsub = lv.nsub[j], sub = blockIdx.x % nsub;
         float* __restrict__ tab = lv.table[j];
-        reinterpret_cast<float2*>(s_xch)[tid] = g_next;   // requested an iteration ago
-        if (j + 1 < lv.n) g_next = *reinterpret_cast<const float2*>(d_out + denc_index(p_load, lv.id[j + 1], levels, level_stride));
-        if (tid < BIN_MAX_SEGS) s_hist[tid] = 0u;
-        __syncthreads();
-        const float2 g = reinterpret_cast<const float2*>(s_xch)[pt_in_wg];
+        unsigned* hist = s_hist[j & 1];
+        const float2 g = g_next;   // requested an iteration ago
+        if (j + 1 < lv.n) g_next = *reinterpret_cast<const float2*>(d_out + denc_index(p_own, lv.id[j + 1], levels, level_stride));
         const Cell c = locate3(xyz, lv.res[j]);
-        // w = pos - floor(pos) is a fractional part, but for pos in [-2^-25, 0) it rounds to exactly 1: rho = inf
-        // there, and such a corner pair never takes the (a, rho a) record form (`pair` below)
-        const float rho = c.w[0] / (1.0f - c.w[0]);
         unsigned seg[4], pos[4], loc[4];
-        float va[4], vb[4], vr[4];
+        bool pair[4];
 #pragma unroll
         for (int yz = 0; yz < 4; ++yz) {
             const unsigned cy = (yz & 2) ? c.hi[1] : c.lo[1], cz = (yz & 1) ? c.hi[2] : c.lo[2];
-            const float wy = (yz & 2) ? c.w[1] : 1.0f - c.w[1], wz = (yz & 1) ? c.w[2] : 1.0f - c.w[2];
             // the hash is linear in x: unless x wraps around the grid or the 32-bit sum around zero, the high-x
             // corner's sum is the low-x one's plus one, and so is its remainder
             const unsigned h_yz = cy * 2654435761u + cz * 805459861u, h_lo = c.lo[0] + h_yz;
             const unsigned r_lo = row_of_sum(h_lo, size, magic);
             unsigned r_hi = r_lo + 1 == size ? 0u : r_lo + 1;
             if (c.hi[0] != c.lo[0] + 1 || h_lo == 0xffffffffu) r_hi = row_of_sum(c.hi[0] + h_yz, size, magic);
-            const float w_lo = ((1.0f - c.w[0]) * wy) * wz, w_hi = (c.w[0] * wy) * wz;
             seg[yz] = r_lo / BIN_SEG_ROWS;
             loc[yz] = r_lo % BIN_SEG_ROWS;
-            const bool pair = r_hi == r_lo + 1 && loc[yz] != BIN_SEG_ROWS - 1 && c.w[0] < 1.0f;
-            va[yz] = w_lo * g.x;
-            vb[yz] = w_lo * g.y;
-            vr[yz] = pair ? rho : 0.0f;
-            if (valid && !pair) {
+            // w = pos - floor(pos) is a fractional part, but for pos in [-2^-25, 0) it rounds to exactly 1: rho = inf
+            // there, and such a corner pair never takes the (a, rho a) record form
+            pair[yz] = r_hi == r_lo + 1 && loc[yz] != BIN_SEG_ROWS - 1 && c.w[0] < 1.0f;
+            if (valid && !pair[yz]) {
+                const float wy = (yz & 2) ? c.w[1] : 1.0f - c.w[1], wz = (yz & 1) ? c.w[2] : 1.0f - c.w[2];
+                const float w_hi = (c.w[0] * wy) * wz;
                 atomicAdd(tab + 2 * (size_t)r_hi, w_hi * g.x);
                 atomicAdd(tab + 2 * (size_t)r_hi + 1, w_hi * g.y);
             }
-            pos[yz] = valid ? atomicAdd(&s_hist[seg[yz]], 1u) : 0u;
+            pos[yz] = valid ? atomicAdd(&hist[seg[yz]], 1u) : 0u;
         }
-        __syncthreads();
+        __syncthreads();   // B
         if (tid < nseg) {
-            const unsigned cnt = s_hist[tid], padded = (cnt + BIN_RUN - 1) & ~(unsigned)(BIN_RUN - 1);
+            const unsigned cnt = hist[tid], padded = (cnt + BIN_RUN - 1) & ~(unsigned)(BIN_RUN - 1);
             s_gbase[tid] = cnt ? atomicAdd(&counters[lv.cnt_first[j] + sub * nseg + tid], padded) : 0u;
         }
+        if (tid >= BIN_MAX_SEGS && tid < 2 * BIN_MAX_SEGS) s_hist[(j + 1) & 1][tid - BIN_MAX_SEGS] = 0u;   // last read a level ago
         if (tid >= 2 * BIN_MAX_SEGS && tid < 3 * BIN_MAX_SEGS) {   // another wave than the one reserving queue space:
             const int k = tid - 2 * BIN_MAX_SEGS;                   // prefix sums of the padded run lengths, one lane per segment
-            const unsigned len = k < nseg ? (s_hist[k] + BIN_RUN - 1) & ~(unsigned)(BIN_RUN - 1) : 0u;
+            const unsigned len = k < nseg ? (hist[k] + BIN_RUN - 1) & ~(unsigned)(BIN_RUN - 1) : 0u;
             unsigned incl = len;
 #pragma unroll
             for (int d = 1; d < 64; d *= 2) {
@@ -348,7 +351,18 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
             s_start[k] = incl - len;
             if (k == BIN_MAX_SEGS - 1) s_start[BIN_MAX_SEGS] = incl;
         }
-        __syncthreads();
+        // the records' values, while the reservation is on its way
+        const float rho = c.w[0] / (1.0f - c.w[0]);
+        float va[4], vb[4], vr[4];
+#pragma unroll
+        for (int yz = 0; yz < 4; ++yz) {
+            const float wy = (yz & 2) ? c.w[1] : 1.0f - c.w[1], wz = (yz & 1) ? c.w[2] : 1.0f - c.w[2];
+            const float w_lo = ((1.0f - c.w[0]) * wy) * wz;
+            va[yz] = w_lo * g.x;
+            vb[yz] = w_lo * g.y;
+            vr[yz] = pair[yz] ? rho : 0.0f;
+        }
+        __syncthreads();   // C
         if (valid) {
 #pragma unroll
             for (int yz = 0; yz < 4; ++yz) {
@@ -371,21 +385,22 @@ __global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* _
             }
         }
         if (tid < nseg) {   // empty records up to the end of the run's last line (row BIN_SEG_ROWS is the image's spare row)
-            const unsigned cnt = s_hist[tid], padded = (cnt + BIN_RUN - 1) & ~(unsigned)(BIN_RUN - 1);
+            const unsigned cnt = hist[tid], padded = (cnt + BIN_RUN - 1) & ~(unsigned)(BIN_RUN - 1);
             for (unsigned k = cnt; k < padded; ++k) {
                 const unsigned gq = s_gbase[tid] + k;
                 s_dest[s_start[tid] + k] = gq < cap ? (tid * nsub + sub) * cap + gq : BIN_NO_DEST;
                 s_rec[s_start[tid] + k] = make_float4(__uint_as_float((unsigned)BIN_SEG_ROWS), 0.0f, 0.0f, 0.0f);
             }
         }
-        __syncthreads();
+        __syncthreads();   // D
         const unsigned n_rec = s_start[BIN_MAX_SEGS];
         float4* __restrict__ q = queues + lv.q_off[j];
         for (unsigned i = tid; i < n_rec; i += BIN_PTS) {
             const unsigned d = s_dest[i];
             if (d != BIN_NO_DEST) q[d] = s_rec[i];
         }
-        __syncthreads();
+        // no barrier here: whatever the next level writes before its barrier B (the other histogram) is not read by
+        // this copy-out, and nothing passes B before every wave has finished it
     }
 }
 
