@@ -305,7 +305,7 @@ def gpu_main(args):
             "dist": who,
         }
     elif rank == 0:
-        roof = kernel_roofline(model, min(rays, RAYS_SINGLE) if chunk is None else min(rays, chunk), dev)
+        roof = kernel_roofline(model, min(rays, RAYS_SINGLE) if chunk is None else min(rays, chunk), dev, probe=not args.no_probe)
         result = {
             "metric": "rays/sec fwd+bwd (lego 800x800, 64 coarse + 128 fine)",
             "value": world * rays * args.steps / dt,
@@ -392,7 +392,7 @@ def sustained_mfma_probe():
         return None
 
 
-def kernel_roofline(model, rays, dev):
+def kernel_roofline(model, rays, dev, probe=True):
     """Time the three MLP kernels alone (HIP events on the launch stream) at the
     fine-pass size and report the one that takes most of the step."""
     from nerf_amd import ops
@@ -444,7 +444,7 @@ def kernel_roofline(model, rays, dev):
     hbm_bound = gbs / PEAK_HBM_GBS >= tflops / peak_mfma
     per_kernel = {k: {"ms": v[0] * 1e3, "tflops": v[1] * P / v[0] / 1e12, "mfma_frac": v[1] * P / v[0] / 1e12 / peak_mfma,
                       "gbs": v[2] * P / v[0] / 1e9, "hbm_frac": v[2] * P / v[0] / 1e9 / PEAK_HBM_GBS} for k, v in kernels.items()}
-    sustained = sustained_mfma_probe()
+    sustained = sustained_mfma_probe() if probe else None
     if sustained:
         for v in per_kernel.values():
             v["frac_of_sustained_mfma"] = v["tflops"] * MFMA_PER_PRODUCT / sustained["f16_tflops"]
@@ -574,6 +574,8 @@ def main():
                     help="vanilla = the headline workload; ngp = the hash-grid variant (secondary line)")
     ap.add_argument("--cpu-rays", type=int, default=4096, help="ray batch of the CPU baseline's all-thread leg (the batch the metric is quoted on)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="skip the sustained-MFMA probe (a child process: under a profiler it would be traced as well)")
     ap.add_argument("--occupancy", type=float, default=None,
                     help="hash-grid model: skip the samples in empty cells of a synthetic occupancy grid (a ball of occupied cells) "
                          "that keeps about this fraction of the samples; rides along as 'secondary_skip_empty' at 0.2 by default")

@@ -114,91 +114,91 @@ __global__ __launch_bounds__(256, 3) void ngp_fwd_kernel(const float* __restrict
     const long long P32 = (P + 31) / 32 * 32, tiles = P32 / 32;
 #pragma unroll 1
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < tiles; tile += (long long)gridDim.x * 4) {
-    // the lane index is opaque per tile: otherwise every lane's weight offsets (and the weights) are formed in front of
-    // the loop, hundreds of registers of them
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int h = lane >> 5;
-    NgpIdx ix;
-    ix.lane = lane; ix.tile = tile; ix.h = h; ix.gp = tile * 32 + (lane & 31); ix.valid = ix.gp < P;
-    ix.lp = ix.valid ? ix.gp : P - 1; ix.P32 = P32;
-    auto pk_at = [&](int packed_off) { return packed_off >= np::S_BD1 ? s_w + W_FWD + (packed_off - np::S_BD1) : s_w + (packed_off - np::F_D1); };
-    const TileBuf tb = tile_buf(s_tile[wave], lane);
-    // ---- hash encoding: levels 8h .. 8h+7 of this lane's point, gathered level by level by the launch before
-    // this one (enc: [16][P32][2]); 32 consecutive lanes read 256 contiguous bytes per level
-    f32x16 e[1];
+        // the lane index is opaque per tile: otherwise every lane's weight offsets (and the weights) are formed in front of
+        // the loop, hundreds of registers of them
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int h = lane >> 5;
+        NgpIdx ix;
+        ix.lane = lane; ix.tile = tile; ix.h = h; ix.gp = tile * 32 + (lane & 31); ix.valid = ix.gp < P;
+        ix.lp = ix.valid ? ix.gp : P - 1; ix.P32 = P32;
+        auto pk_at = [&](int packed_off) { return packed_off >= np::S_BD1 ? s_w + W_FWD + (packed_off - np::S_BD1) : s_w + (packed_off - np::F_D1); };
+        const TileBuf tb = tile_buf(s_tile[wave], lane);
+        // ---- hash encoding: levels 8h .. 8h+7 of this lane's point, gathered level by level by the launch before
+        // this one (enc: [16][P32][2]); 32 consecutive lanes read 256 contiguous bytes per level
+        f32x16 e[1];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float2 v = *reinterpret_cast<const float2*>(enc + 2 * ((8 * h + j) * ix.P32 + ix.lp));
-        e[0][2 * j] = v.x;
-        e[0][2 * j + 1] = v.y;
-    }
-    if (SAVE) {
-        // the saved encoding leaves as whole rows too: lane (p, h) holds features 16h .. 16h+15 of point p, which go into
-        // row p of the wave's transposition buffer, and the buffer goes out 128 contiguous bytes per 8 lanes
-        const unsigned wr_e = lds_addr(s_tile[wave] + (lane & 31) * TILE_LD + 16 * h);
-        static_for<0, 4>([&](auto cq) {
-            constexpr int q = decltype(cq)::value;
-            lds_write4<16 * q>(wr_e, f32x4{e[0][4 * q], e[0][4 * q + 1], e[0][4 * q + 2], e[0][4 * q + 3]});
-        });
-        f32x4 v[4];
-        static_for<0, 4>([&](auto ck) { v[ck] = lds_read4<8 * decltype(ck)::value * TILE_LD * 4>(tb.rd); });
-        lgkm_wait();
-        float* rows0 = ws + ix.P32 * nw::E + ix.tile * (32 * 32);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            asm volatile("" : "+v"(v[k]));
-            __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(rows0 + (size_t)(8 * k + tb.row) * 32 + tb.col));
+        for (int j = 0; j < 8; ++j) {
+            const float2 v = *reinterpret_cast<const float2*>(enc + 2 * ((8 * h + j) * ix.P32 + ix.lp));
+            e[0][2 * j] = v.x;
+            e[0][2 * j + 1] = v.y;
         }
-    }
-    // ---- density MLP: raw = W2 relu(W1 e + b1) + b2        (FastNGPNeRF.py:90)
-    f32x16 hd[2];
-    fill_rows<2>(hd, pk_at(np::S_BD1), h);
-    dense<1, 2>(pk_at(np::F_D1), e, hd, lane);
-    relu_tiles<2>(hd);
-    // every saved matrix leaves right after it is formed, under the layers that follow
-    if (SAVE) save_tiles<2>(tb, ws + ix.P32 * nw::HD + ix.tile * (32 * 64), 64, hd);
-    f32x16 cin[2];   // [raw | pe(dir)]
-    {
-        f32x16 raw[1];
-        fill_rows<1>(raw, pk_at(np::S_BD2), h);
-        dense<2, 1>(pk_at(np::F_D2), hd, raw, lane);
-        cin[0] = raw[0];
-        if (SAVE) save_tiles<1>(tb, ws + ix.P32 * nw::RAW + ix.tile * (32 * 32), 32, raw);
-    }
-    if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(cin[0][0] + 1.5f);   // row 0 lives in lane half 0, register 0  (:91-92)
-    // ---- view direction: normalise, encode with 4 bands (:98-99); zeros when no directions are given (:100-103)
-    {
-        f32x16 de[1];
-        if (dirs) {
-            const long long dr = ix.lp / dirs_div;
-            float d0 = dirs[3 * dr], d1 = dirs[3 * dr + 1], d2 = dirs[3 * dr + 2];
-            const float n = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
-            d0 /= n; d1 /= n; d2 /= n;
-            pe_tiles<1, 4>(de, d0, d1, d2, h);
-        } else {
-            zero_tiles<1>(de);
-        }
-        cin[1] = de[0];
-        if (SAVE) save_tiles<1>(tb, ws + ix.P32 * nw::DE + ix.tile * (32 * 32), 32, de);
-    }
-    // ---- colour MLP: sigmoid(W4 relu(W3 [feat | pe] + Wskip feat + b3) + b4)   (:105-108)
-    f32x16 hc[2];
-    fill_rows<2>(hc, pk_at(np::S_BC1), h);
-    dense<2, 2>(pk_at(np::F_C1), cin, hc, lane);
-    relu_tiles<2>(hc);
-    if (SAVE) {
-        save_tiles<2>(tb, ws + ix.P32 * nw::HC + ix.tile * (32 * 64), 64, hc);
-        unsigned* mask = reinterpret_cast<unsigned*>(ws + ix.P32 * nw::MASK) + ix.tile * 128 + lane;
-        mask[0] = relu_bits2(hd);
-        mask[64] = relu_bits2(hc);
-    }
+        if (SAVE) {
+            // the saved encoding leaves as whole rows too: lane (p, h) holds features 16h .. 16h+15 of point p, which go into
+            // row p of the wave's transposition buffer, and the buffer goes out 128 contiguous bytes per 8 lanes
+            const unsigned wr_e = lds_addr(s_tile[wave] + (lane & 31) * TILE_LD + 16 * h);
+            static_for<0, 4>([&](auto cq) {
+                constexpr int q = decltype(cq)::value;
+                lds_write4<16 * q>(wr_e, f32x4{e[0][4 * q], e[0][4 * q + 1], e[0][4 * q + 2], e[0][4 * q + 3]});
+            });
+            f32x4 v[4];
+            static_for<0, 4>([&](auto ck) { v[ck] = lds_read4<8 * decltype(ck)::value * TILE_LD * 4>(tb.rd); });
+            lgkm_wait();
+            float* rows0 = ws + ix.P32 * nw::E + ix.tile * (32 * 32);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v = dot_rows<2>(hc, pk_at(np::S_WC2 + 64 * c), h) + pk_at(np::S_BC2)[c];
-        if (ix.valid && h == 0) rgb[3 * ix.gp + c] = sigmoid_f(v);
-    }
-    // the wave's accesses to its transposition buffer are in program order; nothing else is shared between tiles
+            for (int k = 0; k < 4; ++k) {
+                asm volatile("" : "+v"(v[k]));
+                __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(rows0 + (size_t)(8 * k + tb.row) * 32 + tb.col));
+            }
+        }
+        // ---- density MLP: raw = W2 relu(W1 e + b1) + b2        (FastNGPNeRF.py:90)
+        f32x16 hd[2];
+        fill_rows<2>(hd, pk_at(np::S_BD1), h);
+        dense<1, 2>(pk_at(np::F_D1), e, hd, lane);
+        relu_tiles<2>(hd);
+        // every saved matrix leaves right after it is formed, under the layers that follow
+        if (SAVE) save_tiles<2>(tb, ws + ix.P32 * nw::HD + ix.tile * (32 * 64), 64, hd);
+        f32x16 cin[2];   // [raw | pe(dir)]
+        {
+            f32x16 raw[1];
+            fill_rows<1>(raw, pk_at(np::S_BD2), h);
+            dense<2, 1>(pk_at(np::F_D2), hd, raw, lane);
+            cin[0] = raw[0];
+            if (SAVE) save_tiles<1>(tb, ws + ix.P32 * nw::RAW + ix.tile * (32 * 32), 32, raw);
+        }
+        if (ix.valid && h == 0) sigma[ix.gp] = softplus_f(cin[0][0] + 1.5f);   // row 0 lives in lane half 0, register 0  (:91-92)
+        // ---- view direction: normalise, encode with 4 bands (:98-99); zeros when no directions are given (:100-103)
+        {
+            f32x16 de[1];
+            if (dirs) {
+                const long long dr = ix.lp / dirs_div;
+                float d0 = dirs[3 * dr], d1 = dirs[3 * dr + 1], d2 = dirs[3 * dr + 2];
+                const float n = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+                d0 /= n; d1 /= n; d2 /= n;
+                pe_tiles<1, 4>(de, d0, d1, d2, h);
+            } else {
+                zero_tiles<1>(de);
+            }
+            cin[1] = de[0];
+            if (SAVE) save_tiles<1>(tb, ws + ix.P32 * nw::DE + ix.tile * (32 * 32), 32, de);
+        }
+        // ---- colour MLP: sigmoid(W4 relu(W3 [feat | pe] + Wskip feat + b3) + b4)   (:105-108)
+        f32x16 hc[2];
+        fill_rows<2>(hc, pk_at(np::S_BC1), h);
+        dense<2, 2>(pk_at(np::F_C1), cin, hc, lane);
+        relu_tiles<2>(hc);
+        if (SAVE) {
+            save_tiles<2>(tb, ws + ix.P32 * nw::HC + ix.tile * (32 * 64), 64, hc);
+            unsigned* mask = reinterpret_cast<unsigned*>(ws + ix.P32 * nw::MASK) + ix.tile * 128 + lane;
+            mask[0] = relu_bits2(hd);
+            mask[64] = relu_bits2(hc);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = dot_rows<2>(hc, pk_at(np::S_WC2 + 64 * c), h) + pk_at(np::S_BC2)[c];
+            if (ix.valid && h == 0) rgb[3 * ix.gp + c] = sigmoid_f(v);
+        }
+        // the wave's accesses to its transposition buffer are in program order; nothing else is shared between tiles
     }
 }
 
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void ngp_bwd_fused_kernel(const float* __re
         // The packed weights and every lane's offsets into them and into the saved matrices are the same for every tile:
         // left to itself the compiler forms all of them (some 200 registers per lane of weights, as many of 64-bit
         // addresses) in front of the loop and spills.  The lane index is made opaque per tile, so that addresses are
-        // formed where they are used and the weights are read again per tile, from L2.
+        // formed where they are used and the weights are read again per tile (from LDS, see above).
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int h = lane >> 5, p = lane & 31;

@@ -6,16 +6,16 @@ set -e
 OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu > "$OUT/trace.log" 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu --no-probe > "$OUT/trace.log" 2>&1
 python3 tools/summarize_trace.py "$(ls "$OUT"/trace/*/*_kernel_trace.csv | head -1)" > "$OUT/bench_kernels_by_grid.txt"
 cp "$(ls "$OUT"/trace/*/*_kernel_stats.csv | head -1)" "$OUT/bench_kernel_stats.csv"
 run() {  # name, program, counters...
   name=$1; prog=$2; shift; shift
   timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 $prog > "$OUT/$name.log" 2>&1
 }
-run mfma "bench.py --steps 3 --warmup 1 --no-cpu" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
-run fetch "bench.py --steps 3 --warmup 1 --no-cpu" FETCH_SIZE
-run write "bench.py --steps 3 --warmup 1 --no-cpu" WRITE_SIZE
+run mfma "bench.py --steps 3 --warmup 1 --no-cpu --no-probe" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
+run fetch "bench.py --steps 3 --warmup 1 --no-cpu --no-probe" FETCH_SIZE
+run write "bench.py --steps 3 --warmup 1 --no-cpu --no-probe" WRITE_SIZE
 run kfetch "bench_kernels.py" FETCH_SIZE
 run kwrite "bench_kernels.py" WRITE_SIZE
 python3 tools/summarize_pmc.py "$OUT"/mfma/*/*_counter_collection.csv "$OUT"/fetch/*/*_counter_collection.csv "$OUT"/write/*/*_counter_collection.csv > "$OUT/bench_pmc_summary.txt"
