@@ -458,7 +458,7 @@ def kernel_roofline(model, rays, dev, probe=True):
             "mfma_frac": tflops / peak_mfma, "hbm_frac": gbs / PEAK_HBM_GBS, "executed_f16_tflops": tflops * MFMA_PER_PRODUCT,
             "fp32_equivalent_tflops": tflops,
             "frac_of_six_mfma_roofline": tflops / (PEAK_F16_MATRIX_TFLOPS / 6),
-            "note_six": "until the middle of round 2 a product was six bf16 MFMAs (roofline 416.7 fp32-equivalent TFLOP/s, kernels at "
+            "note_six": "an earlier version formed a product from six bf16 MFMAs (roofline 416.7 fp32-equivalent TFLOP/s, kernels at "
                         "0.49-0.54 of it); halving the MFMAs per product halves the executed-MFMA fraction of the same time, so "
                         "the fp32-equivalent rate against that earlier roofline is given for comparison",
             "mfma_busy_pmc": busy or None, "traffic_stale": stale,
