@@ -100,6 +100,11 @@ def main():
     t = timeit(lambda: lib.nerf_pdf_sample(*a_ps))
     report("pdf_sample (64 -> +128)", R * (N * 8 + NF * 4 + 24) + R * NA * 16 + R * NF * 4, t,
            "read z,weights,u,rays; write z_fine,z_all,pts")
+    uf_sorted = torch.sort(uf, dim=-1).values
+    a_ps2 = a_ps[:4] + (L.ptr(uf_sorted),) + a_ps[5:]
+    t = timeit(lambda: lib.nerf_pdf_sample(*a_ps2))
+    report("pdf_sample (64 -> +128), uniforms sorted", R * (N * 8 + NF * 4 + 24) + R * NA * 16 + R * NF * 4, t,
+           "the same with sorted uniforms (deterministic renders): the kernel's sort is skipped")
 
     x = pts.reshape(-1, 3)
     P = x.shape[0]

@@ -237,16 +237,37 @@ __device__ __forceinline__ void wave_bitonic_sort(float (&v)[EPL], int lane) {
     });
 }
 
-template <int EPL>
+struct __attribute__((packed, aligned(4))) Float3 {   // one 12-byte store
+    float x, y, z;
+};
+
+// Number of entries of the non-decreasing a[0..n) that are <= v (LE) or < v: a branch-free binary search whose steps
+// are the same for every lane (top = the largest power of two <= n).
+template <bool LE>
+__device__ __forceinline__ int count_below(const float* a, int n, int top, float v) {
+    int lo = 0;
+    for (int step = top; step >= 1; step >>= 1) {
+        const int mid = lo + step;
+        const float t = a[min(mid, n) - 1];
+        if (mid <= n && (LE ? t <= v : t < v)) lo = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int pow2_floor(int n) { return 1 << (31 - __builtin_clz(n)); }
+
+// NC_MAX: the coarse depths a wave's LDS arrays hold (128 or PDF_MAX_NC).  The kernel lives on its LDS round trips
+// (scan, three rounds of binary searches): with arrays sized for 256 + 1024 depths four workgroups fit a CU, sized for
+// the usual 64 + 128 eight do, the most its waves allow.
+template <int EPL, int NC_MAX>
 __global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z,
     const float* __restrict__ weights, const float* __restrict__ u, int64_t R, int Nc, int Nf,
     float* __restrict__ z_fine, int32_t* __restrict__ idx_out, float* __restrict__ z_all, float* __restrict__ pts) {
-    __shared__ float s_scan[PDF_WAVES][2][PDF_MAX_NC];
-    __shared__ float s_bins[PDF_WAVES][PDF_MAX_NC];
-    __shared__ float s_zc[PDF_WAVES][PDF_MAX_NC];
+    __shared__ float s_scan[PDF_WAVES][2][NC_MAX];
+    __shared__ float s_bins[PDF_WAVES][NC_MAX];
+    __shared__ float s_zc[PDF_WAVES][NC_MAX];
     __shared__ float s_fine[PDF_WAVES][64 * EPL];
-    __shared__ float s_sorted[PDF_WAVES][PDF_MAX_ALL];
+    __shared__ float s_sorted[PDF_WAVES][64 * EPL + NC_MAX];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * PDF_WAVES + wv;
     if (ray >= R) return;   // whole wave
@@ -293,6 +314,7 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
     }
     wave_lds_sync();
 
+    const int top_nb = pow2_floor(nb), top_nc = pow2_floor(Nc), top_nf = pow2_floor(Nf);
     float zf[EPL];
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
@@ -300,11 +322,7 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
         zf[k] = __builtin_inff();   // padding sorts to the end
         if (f < Nf) {
             const float uu = u[ray * Nf + f];
-            int lo = 0, hi = nb;  // first entry with cdf > uu
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
-            }
+            const int lo = count_below<true>(cdf, nb, top_nb, uu);   // first entry with cdf > uu
             const int below = max(lo - 1, 0), above = min(lo, nb - 1);
             const float c_lo = cdf[below], c_hi = cdf[above];
             const float b_lo = s_bins[wv][below], b_hi = s_bins[wv][above];
@@ -316,31 +334,29 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
             if (idx_out) idx_out[ray * Nf + f] = lo;
         }
     }
-    wave_bitonic_sort<EPL>(zf, lane);
+    // The depths come out in the order of their uniforms (the inverse cdf is monotone): a caller that passes sorted
+    // uniforms -- an evenly spaced or stratified set, as deterministic renders do -- needs no sort, a third of this
+    // kernel's instructions.  Checked on the depths themselves, so nothing is assumed: element e against e + 1.
+    bool in_order = true;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        float next = __shfl_down(zf[k], 1, 64);
+        if (lane == 63) next = k + 1 < EPL ? lane_value(zf[k + 1 < EPL ? k + 1 : k], 0) : __builtin_inff();
+        in_order = in_order && zf[k] <= next;   // false for a NaN: the sort decides
+    }
+    if (!__all(in_order)) wave_bitonic_sort<EPL>(zf, lane);
 #pragma unroll
     for (int k = 0; k < EPL; ++k) s_fine[wv][k * 64 + lane] = zf[k];
     wave_lds_sync();
     const int na = Nc + Nf;
     for (int i = lane; i < Nc; i += 64) {   // coarse depth i: fine depths strictly below it come first
         const float v = s_zc[wv][i];
-        int lo = 0, hi = Nf;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_fine[wv][mid] < v) lo = mid + 1; else hi = mid;
-        }
-        s_sorted[wv][i + lo] = v;
+        s_sorted[wv][i + count_below<false>(s_fine[wv], Nf, top_nf, v)] = v;
     }
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {         // fine depth e: coarse depths up to and including it come first
         const int e = k * 64 + lane;
-        if (e < Nf) {
-            int lo = 0, hi = Nc;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_zc[wv][mid] <= zf[k]) lo = mid + 1; else hi = mid;
-            }
-            s_sorted[wv][e + lo] = zf[k];
-        }
+        if (e < Nf) s_sorted[wv][e + count_below<true>(s_zc[wv], Nc, top_nc, zf[k])] = zf[k];
     }
     wave_lds_sync();
     if (z_all)
@@ -352,12 +368,11 @@ __global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
             o[k] = rays_o[3 * ray + k];
             d[k] = rays_d[3 * ray + k];
         }
-        // flat float f of the ray's points is coordinate f%3 of sample f/3: coalesced stores
-        for (int f = lane; f < 3 * na; f += 64) {
-            const int smp = f / 3, c = f - 3 * smp;
-            const float oc = c == 0 ? o[0] : c == 1 ? o[1] : o[2];
-            const float dc = c == 0 ? d[0] : c == 1 ? d[1] : d[2];
-            pts[ray * na * 3 + f] = oc + dc * s_sorted[wv][smp];
+        // a lane per sample, 12 contiguous bytes each: 64 lanes store 768 contiguous bytes per instruction
+        float* out = pts + ray * na * 3;
+        for (int smp = lane; smp < na; smp += 64) {
+            const float t = s_sorted[wv][smp];
+            *reinterpret_cast<Float3*>(out + 3 * smp) = Float3{o[0] + d[0] * t, o[1] + d[1] * t, o[2] + d[2] * t};
         }
     }
 }
@@ -467,9 +482,15 @@ extern "C" int nerf_pdf_sample(const float* rays_o, const float* rays_d, const f
     NERF_REQUIRE(Nf >= 1 && Nc + Nf <= PDF_MAX_ALL, "nerf_pdf_sample: Nc+Nf=%d exceeds %d", Nc + Nf, PDF_MAX_ALL);
     NERF_REQUIRE(R >= 0, "nerf_pdf_sample: R=%lld", (long long)R);
     const dim3 grid((unsigned)ceil_div(R, PDF_WAVES)), block(PDF_WAVES * 64);
-#define PDF_LAUNCH(EPL)                                                                                              \
-    hipLaunchKernelGGL(pdf_sample_kernel<EPL>, grid, block, 0, (hipStream_t)stream, rays_o, rays_d, z, weights, u, R, \
-                       Nc, Nf, z_fine, idx, z_all, pts)
+#define PDF_LAUNCH(EPL)                                                                                                      \
+    do {                                                                                                                     \
+        if (Nc <= 128)                                                                                                       \
+            hipLaunchKernelGGL((pdf_sample_kernel<EPL, 128>), grid, block, 0, (hipStream_t)stream, rays_o, rays_d, z, weights, \
+                               u, R, Nc, Nf, z_fine, idx, z_all, pts);                                                       \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((pdf_sample_kernel<EPL, PDF_MAX_NC>), grid, block, 0, (hipStream_t)stream, rays_o, rays_d, z,   \
+                               weights, u, R, Nc, Nf, z_fine, idx, z_all, pts);                                              \
+    } while (0)
     if (Nf <= 64) PDF_LAUNCH(1);
     else if (Nf <= 128) PDF_LAUNCH(2);
     else if (Nf <= 256) PDF_LAUNCH(4);

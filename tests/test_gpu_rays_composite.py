@@ -109,6 +109,13 @@ def test_pdf_sample_indices_bit_exact(dev, Nc, Nf):
     u = torch.rand(R, Nf, generator=gen)
     u[2, 0] = 0.0
     u[3] = 1.0 - 2.0 ** -24                        # the last bin: reads the final cdf entry
+    # uniforms that arrive sorted need no sort in the kernel (it checks the depths, not the uniforms): evenly spaced,
+    # sorted random with ties, and sorted but for the last pair (which must still be sorted)
+    u[4] = torch.linspace(0.0, 1.0 - 2.0 ** -24, Nf)
+    u[5:40] = torch.sort(u[5:40], dim=-1).values
+    u[6, Nf // 2:] = u[6, Nf // 2]
+    if Nf > 1:
+        u[7, -2:] = u[7, -2:].flip(0)
     zf_o, idx_o, zall_o = O.sample_pdf(z, w, u)
     zf, idx, z_all, pts = ops.pdf_sample(o.to(dev), d.to(dev), z.to(dev), w.to(dev), u.to(dev), want_idx=True)
     assert torch.equal(idx.cpu(), idx_o)          # sample indices: bit-exact
