@@ -259,7 +259,7 @@ __device__ __forceinline__ int pow2_floor(int n) { return 1 << (31 - __builtin_c
 // (scan, three rounds of binary searches): with arrays sized for 256 + 1024 depths four workgroups fit a CU, sized for
 // the usual 64 + 128 eight do, the most its waves allow.
 template <int EPL, int NC_MAX>
-__global__ __launch_bounds__(PDF_WAVES * 64) void pdf_sample_kernel(
+__global__ __launch_bounds__(PDF_WAVES * 64, (EPL <= 2 && NC_MAX <= 128) ? 8 : 1) void pdf_sample_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z,
     const float* __restrict__ weights, const float* __restrict__ u, int64_t R, int Nc, int Nf,
     float* __restrict__ z_fine, int32_t* __restrict__ idx_out, float* __restrict__ z_all, float* __restrict__ pts) {
