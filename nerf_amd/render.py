@@ -273,6 +273,26 @@ def psnr(x, y):
     return -10.0 * torch.log10(torch.mean((x - y) ** 2))
 
 
+def ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0, win_size: int = 7) -> torch.Tensor:
+    """Mean structural similarity of two images [H,W,C] as the per-view log of the synthetic-scene loop computes it
+    (src/train_nerf.py:174: scikit-image's ``structural_similarity(gt, img, channel_axis=2, data_range=1.0)`` with its
+    defaults): a ``win_size`` x ``win_size`` box window, sample covariances (n / (n - 1)), K1 = 0.01, K2 = 0.03,
+    averaged over the window positions that lie wholly inside the image and then over the channels (Wang et al. 2004).
+    Evaluated in float64 on the tensors' device; a 0-d tensor comes back."""
+    if x.shape != y.shape or x.dim() != 3:
+        raise ValueError("ssim: two images [H,W,C] of one shape, got %s and %s" % (tuple(x.shape), tuple(y.shape)))
+    if min(x.shape[0], x.shape[1]) < win_size:
+        raise ValueError("ssim: the image is smaller than the %d-pixel window" % win_size)
+    a, b = x.permute(2, 0, 1)[None].double(), y.permute(2, 0, 1)[None].double()
+    box = lambda t: torch.nn.functional.avg_pool2d(t, win_size, stride=1)   # valid positions only
+    n = win_size * win_size
+    ua, ub = box(a), box(b)
+    va, vb, vab = (n / (n - 1.0)) * (box(a * a) - ua * ua), (n / (n - 1.0)) * (box(b * b) - ub * ub), (n / (n - 1.0)) * (box(a * b) - ua * ub)
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    s = ((2 * ua * ub + c1) * (2 * vab + c2)) / ((ua * ua + ub * ub + c1) * (va + vb + c2))
+    return s.mean(dim=(0, 2, 3)).mean()
+
+
 def nerf_loss(out: dict, target: torch.Tensor) -> torch.Tensor:
     """MSE of the coarse colour (src/train_nerf_llff.py:116) plus, when a fine pass was rendered, the MSE of the fine
     colour: one fused op (``ops.render_loss``; GPU tensors only, like every op of this package)."""

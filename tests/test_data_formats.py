@@ -120,3 +120,35 @@ def test_llff_wide_images_are_resized_and_transposed(tmp_path):
     ds = LLFFDataset(str(tmp_path))
     assert (ds.H, ds.W) == (30, 100) and ds.focal == 123.5      # the focal length is not rescaled (as in the reference)
     assert tuple(ds[0][0].shape) == (100, 30, 3)                # [W, H, 3]: the reference's permute(2, 1, 0)
+
+
+def test_ssim_follows_the_published_box_window_definition():
+    """scikit-image is not installed here, so the reference's own call (src/train_nerf.py:174) cannot be run:
+    parity unpinned.  Checked against the algorithm scikit-image documents -- uniform_filter means, sample covariances,
+    the border of (win_size - 1) / 2 pixels cropped before averaging -- restated with scipy."""
+    import numpy as np
+    import scipy.ndimage as ndi
+    import torch
+    from nerf_amd.render import ssim
+    rng = np.random.default_rng(0)
+    gt = rng.random((37, 50, 3)).astype(np.float32)
+    img = np.clip(gt + 0.1 * rng.standard_normal(gt.shape).astype(np.float32), 0, 1)
+
+    def restated(a, b, win=7, R=1.0):
+        vals = []
+        for c in range(a.shape[2]):
+            x, y = a[..., c].astype(np.float64), b[..., c].astype(np.float64)
+            f = lambda t: ndi.uniform_filter(t, size=win)
+            ux, uy = f(x), f(y)
+            k = win * win / (win * win - 1.0)
+            vx, vy, vxy = k * (f(x * x) - ux * ux), k * (f(y * y) - uy * uy), k * (f(x * y) - ux * uy)
+            c1, c2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+            s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+            p = (win - 1) // 2
+            vals.append(s[p:-p, p:-p].mean())
+        return float(np.mean(vals))
+
+    got = float(ssim(torch.from_numpy(gt), torch.from_numpy(img)))
+    assert abs(got - restated(gt, img)) < 1e-9
+    assert abs(float(ssim(torch.from_numpy(gt), torch.from_numpy(gt))) - 1.0) < 1e-12
+    assert 0.0 < got < 1.0
