@@ -73,8 +73,8 @@ NGP_NEAR, NGP_FAR = 0.05, 1.2   # src/train_nerf_ngp.py:32-33 (unit-sphere-norma
 RAYS_SINGLE, RAYS_DP = 4096, 65536
 OVERLAP = os.environ.get("NERF_DP_OVERLAP", "1") != "0"   # all-reduce each bucket from its gradient hooks (under backward)
 NGP_WORKLOAD = ("Instant-NGP variant (16 levels, 2^19 rows, 64-wide MLPs), 800x800 camera on the unit sphere, 64 samples, "
-                "%d-ray batch per GPU, one training step incl. Adam over the tables (hip_graph: the step is captured once into a "
-                "HIP graph and replayed)")
+                "%d-ray batch per GPU, one training step incl. Adam over the tables (config.hip_graph true: the step is "
+                "captured once into a HIP graph and replayed; false: issued launch by launch)")
 
 
 def ball_grid(radius, dev, res=32):
