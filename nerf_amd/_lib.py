@@ -109,6 +109,12 @@ def stream_of(t: torch.Tensor):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def require(cond: bool, message: str = "bad argument") -> None:
+    """Argument checks that guard a kernel's indexing: they must hold under ``python -O`` too, so no ``assert``."""
+    if not cond:
+        raise ValueError(message)
+
+
 def need_gpu(*tensors: torch.Tensor) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:

@@ -13,6 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 from .. import ops
+from .._lib import require as _require
 
 
 def camera_rows(poses: torch.Tensor, intrinsics: torch.Tensor) -> torch.Tensor:
@@ -25,7 +26,7 @@ class RayBuffer:
     def __init__(self, images: torch.Tensor, poses: torch.Tensor, intrinsics: torch.Tensor, device,
                  rank: int = 0, world: int = 1, seed: int = 0):
         """images [n,H,W,3] in [0,1]; poses [n,3,4] (or [n,4,4]); intrinsics [n,4] = (fx, fy, cx, cy)."""
-        assert images.dim() == 4 and images.shape[-1] == 3
+        _require(images.dim() == 4 and images.shape[-1] == 3, "images must be [n,H,W,3]")
         self.n, self.H, self.W = images.shape[0], images.shape[1], images.shape[2]
         self.images = images.to(device=device, dtype=torch.float32).contiguous()
         self.cams = camera_rows(poses, intrinsics).to(device)

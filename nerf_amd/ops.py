@@ -34,14 +34,14 @@ def raygen_multi(cams: torch.Tensor, H: int, W: int, cam_id: torch.Tensor, pix: 
     ``pix[r]`` of camera ``cam_id[r]``; with ``images`` [n,H,W,3] the pixels' colours come back as well."""
     L.need_gpu(cams, cam_id, pix, images)
     cams = L.f32c(cams)
-    assert cams.dim() == 2 and cams.shape[1] == 16, f"cams must be [n,16], got {tuple(cams.shape)}"
+    L.require(cams.dim() == 2 and cams.shape[1] == 16, f"cams must be [n,16], got {tuple(cams.shape)}")
     cam_id = cam_id.to(torch.int32).contiguous()
     pix = pix.to(torch.int32).contiguous()
     R = pix.numel()
-    assert cam_id.numel() == R
+    L.require(cam_id.numel() == R, "one camera id per pixel id")
     if images is not None:
         images = L.f32c(images)
-        assert tuple(images.shape) == (cams.shape[0], H, W, 3), f"images must be [{cams.shape[0]},{H},{W},3]"
+        L.require(tuple(images.shape) == (cams.shape[0], H, W, 3), f"images must be [{cams.shape[0]},{H},{W},3]")
     o = torch.empty(R, 3, device=cams.device, dtype=torch.float32)
     d = torch.empty_like(o)
     rgb = torch.empty_like(o) if images is not None else None
@@ -58,7 +58,7 @@ def stratified_sample(rays_o: torch.Tensor, rays_d: torch.Tensor, z_lin: torch.T
     R, N = o.shape[0], zl.numel()
     if u is not None:
         u = L.f32c(u)
-        assert u.shape == (R, N), f"u must be [{R},{N}], got {tuple(u.shape)}"
+        L.require(u.shape == (R, N), f"u must be [{R},{N}], got {tuple(u.shape)}")
     z = torch.empty(R, N, device=o.device, dtype=torch.float32)
     pts = torch.empty(R, N, 3, device=o.device, dtype=torch.float32) if want_pts else None
     L.check(L.lib().nerf_stratified_sample(L.ptr(o), L.ptr(d), L.ptr(zl), L.ptr(u), R, N, L.ptr(z), L.ptr(pts),
@@ -77,7 +77,7 @@ def raygen_sample(c2w, fx, fy, cx, cy, H, W, pix, z_lin, u):
         pix = pix.to(torch.int32).contiguous()
     if u is not None:
         u = L.f32c(u)
-        assert u.shape == (R, N)
+        L.require(u.shape == (R, N), f"u must be [{R},{N}], got {tuple(u.shape)}")
     dev = pose.device
     o = torch.empty(R, 3, device=dev)
     d = torch.empty(R, 3, device=dev)
@@ -247,7 +247,7 @@ class _OccupancyMask(torch.autograd.Function):
     def forward(ctx, sigma, pts, grid, grid_res):
         L.need_gpu(sigma, pts, grid)
         sc, pc = L.f32c(sigma.detach()).reshape(-1), L.f32c(pts.detach()).reshape(-1, 3)
-        assert pc.shape[0] == sc.shape[0], "one point per density"
+        L.require(pc.shape[0] == sc.shape[0], "one point per density")
         if grid.dtype != torch.uint8:
             raise L.NerfHipError("the occupancy grid must be uint8")
         gc = grid.contiguous()
@@ -295,7 +295,7 @@ def occupancy_compact(pts, grid, grid_res: int, dirs=None, dirs_div: int = 1):
     dirs_k = torch.empty(P, 3, device=dev) if dc is not None else None
     count = torch.empty(1, device=dev, dtype=torch.int32)
     if dc is not None:
-        assert dc.shape == ((P + dirs_div - 1) // dirs_div, 3), "dirs must hold one row per dirs_div samples"
+        L.require(dc.shape == ((P + dirs_div - 1) // dirs_div, 3), "dirs must hold one row per dirs_div samples")
     L.check(lib.nerf_occupancy_compact(L.ptr(pc), P, L.ptr(gc), gc.numel(), int(grid_res), L.ptr(dc), int(dirs_div),
                                        L.ptr(work), L.ptr(kept), L.ptr(slot), L.ptr(pts_k), L.ptr(dirs_k), L.ptr(count),
                                        L.stream_of(pc)), "nerf_occupancy_compact")
@@ -312,7 +312,7 @@ class _ExpandKept(torch.autograd.Function):
         L.need_gpu(rgb_k, sigma_k, kept, slot)
         rc, sc = L.f32c(rgb_k.detach()).reshape(-1, 3), L.f32c(sigma_k.detach()).reshape(-1)
         P, K = slot.shape[0], kept.shape[0]
-        assert rc.shape[0] == K and sc.shape[0] == K, "one model output per kept sample"
+        L.require(rc.shape[0] == K and sc.shape[0] == K, "one model output per kept sample")
         rgb = torch.empty(P, 3, device=slot.device)
         sigma = torch.empty(P, device=slot.device)
         L.check(L.lib().nerf_expand_kept(L.ptr(rc), L.ptr(sc), L.ptr(slot), P, L.ptr(rgb), L.ptr(sigma), L.stream_of(slot)),
@@ -351,9 +351,9 @@ class _RenderLoss(torch.autograd.Function):
         f = L.f32c(rgb_fine.detach()) if rgb_fine is not None else None
         w = L.f32c(weights.detach()) if weights is not None else None
         R = c.shape[0]
-        assert c.shape == (R, 3) and t.shape == (R, 3) and R > 0, "rgb and target must be [R,3]"
-        assert f is None or f.shape == (R, 3), "rgb_fine must be [R,3]"
-        assert w is None or (w.dim() == 2 and w.shape[0] == R), "weights must be [R,N]"
+        L.require(c.shape == (R, 3) and t.shape == (R, 3) and R > 0, "rgb and target must be [R,3]")
+        L.require(f is None or f.shape == (R, 3), "rgb_fine must be [R,3]")
+        L.require(w is None or (w.dim() == 2 and w.shape[0] == R), "weights must be [R,N]")
         N = int(w.shape[1]) if w is not None else 0
         work = torch.empty(lib.nerf_render_loss_workspace_floats(R), device=c.device)
         loss = torch.empty((), device=c.device)
@@ -500,12 +500,12 @@ class _VanillaMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, dirs, dirs_div, skip_h_first, grad_mode, *params):
-        assert len(params) == 24
+        L.require(len(params) == 24, "the 8x256 model has 24 parameter tensors")
         L.need_gpu(x, dirs, *params)
         xc, dc = L.f32c(x.detach()), L.f32c(dirs.detach())
         P = xc.shape[0]
-        assert xc.shape == (P, 3), "x must be [N,3]"
-        assert dc.shape == ((P + dirs_div - 1) // dirs_div, 3), "view_dirs must be [N,3] (or one row per ray)"
+        L.require(xc.shape == (P, 3), "x must be [N,3]")
+        L.require(dc.shape == ((P + dirs_div - 1) // dirs_div, 3), "view_dirs must be [N,3] (or one row per ray)")
         packed = vanilla_pack(params, skip_h_first)
         # needs_input_grad mirrors requires_grad even under no_grad, and grad mode is always off in here:
         # the caller's grad mode arrives as an argument
@@ -557,13 +557,13 @@ class _NgpMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dirs, dirs_div, res, grad_mode, *tensors):
         tables, params = tensors[:16], tensors[16:]
-        assert len(tables) == 16 and len(params) == 9
+        L.require(len(tables) == 16 and len(params) == 9, "the hash-grid model has 16 tables and 9 other parameter tensors")
         L.need_gpu(x, dirs, *tensors)
         lib = L.lib()
         xc = L.f32c(x.detach())
         dc = L.f32c(dirs.detach()) if dirs is not None else None
         P = xc.shape[0]
-        assert xc.shape == (P, 3), "x must be [N,3]"
+        L.require(xc.shape == (P, 3), "x must be [N,3]")
         dev = xc.device
         st = L.stream_of(xc)
         tabs = [L.f32c(t.detach()) for t in tables]

@@ -14,6 +14,7 @@ from typing import Optional
 import torch
 
 from . import ops
+from ._lib import require as _require
 
 
 def _eval_model(model, pts, view_dirs, n_per_ray):
@@ -83,7 +84,7 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
         H, W, focal, near_plane = ndc
         rays_o, rays_d = ops.ndc_rays(int(H), int(W), float(focal), float(near_plane), rays_o, rays_d)
     if samples is not None:
-        assert ndc is None, "samples drawn along world-space rays do not fit an NDC render"
+        _require(ndc is None, "samples drawn along world-space rays do not fit an NDC render")
         z, pts = samples
     else:
         if z_lin is None:
