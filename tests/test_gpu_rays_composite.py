@@ -93,7 +93,8 @@ def test_raygen_sample_ragged_sizes(dev, R, N):
     assert torch.equal(z3.cpu(), z_n.expand_as(z3.cpu())) and torch.equal(pts3.cpu(), pts_n)
 
 
-@pytest.mark.parametrize("Nc,Nf", [(64, 128), (17, 5), (3, 1), (100, 200), (64, 400), (256, 768), (66, 128), (65, 7), (67, 64)])
+@pytest.mark.parametrize("Nc,Nf", [(64, 128), (17, 5), (3, 1), (100, 200), (64, 400), (256, 768), (66, 128), (65, 7), (67, 64),
+                                   (128, 64), (129, 64), (128, 896)])   # either side of the kernel's two LDS sizes, and the largest total
 def test_pdf_sample_indices_bit_exact(dev, Nc, Nf):
     from nerf_amd import ops
     gen = torch.Generator().manual_seed(100 + Nc)
