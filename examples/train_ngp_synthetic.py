@@ -6,6 +6,9 @@ ReduceLROnPlateau handing over to CosineAnnealingLR, an occupancy grid refreshed
 once the grid exists -- the samples in its empty cells skipped.
 
     python examples/train_ngp_synthetic.py --steps 1500
+    python examples/train_ngp_synthetic.py --steps 1500 --graph    # the step replayed from a HIP graph (densities in
+                                                                   # empty cells zeroed instead of their samples skipped:
+                                                                   # a captured step's sizes cannot depend on the data)
 """
 import argparse
 import math
@@ -20,7 +23,8 @@ from nerf_amd.Camera import Camera  # noqa: E402
 from nerf_amd.data.ray_buffer import RayBuffer  # noqa: E402
 from nerf_amd.models.FastNGPNeRF import FastNGPNeRF  # noqa: E402
 from nerf_amd.optim import FusedAdam  # noqa: E402
-from nerf_amd.render import get_density_grid, ngp_loss, psnr, render_image, render_rays  # noqa: E402
+from nerf_amd.graph import GraphedStep  # noqa: E402
+from nerf_amd.render import get_density_grid, ngp_loss, psnr, render_image, render_rays, train_step  # noqa: E402
 from nerf_amd.utils.get_rays import evaluate_fake_radiance_field_complex  # noqa: E402
 
 SHRINK = 2.5            # the field's torus (radius 1.3 overall) fits the unit cube at 1 / 2.5
@@ -59,6 +63,7 @@ def main():
     ap.add_argument("--reg", type=float, default=0.0,
                     help="weight of the opacity term mean |1 - sum w| (the reference: 0.05, for captured scenes that are opaque along "
                          "every ray; this field is mostly empty space, where the term fills the background with black density)")
+    ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph and replay it")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -70,21 +75,45 @@ def main():
     held_o, held_d = held_cam.get_rays()
 
     model = FastNGPNeRF().to(dev)
-    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15)
+    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, capturable=args.graph)
     plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=2)
     cosine = None
     grid = None
     window, window_n = torch.zeros((), device=dev), 0
+    graphed = None
+    if args.graph:
+        # the captured step reads these tensors; every iteration copies its batch, its uniforms and the current grid into them
+        s_o, s_d, s_t = (torch.empty(args.rays, 3, device=dev) for _ in range(3))
+        s_u = torch.empty(args.rays, n_samples, device=dev)
+        s_grid = torch.ones(args.grid_res ** 3, dtype=torch.uint8, device=dev)   # everything occupied until the first refresh
+        z_lin = torch.linspace(NEAR, FAR, n_samples).to(dev)
+
+        def load(_=None):
+            o, d, t = buf.next_batch(args.rays)
+            s_o.copy_(o), s_d.copy_(d), s_t.copy_(t), s_u.uniform_()
+
+        def captured():
+            opt.zero_grad(set_to_none=False)
+            loss = train_step(model, s_o, s_d, s_t, NEAR, FAR, n_samples, loss_fn=lambda out, t: ngp_loss(out, t, reg=args.reg),
+                              t_rand=s_u, z_lin=z_lin, density_grid=s_grid, grid_res=args.grid_res)
+            opt.step()
+            return loss
+
+        graphed = GraphedStep(captured, warmup=3, optimizers=[opt], prepare=load)
     torch.cuda.synchronize()
     t0 = time.time()
-    for step in range(1, args.steps + 1):
-        rays_o, rays_d, target = buf.next_batch(args.rays)
-        opt.zero_grad(set_to_none=False)
-        out = render_rays(model, rays_o, rays_d, NEAR, FAR, n_samples, density_grid=grid, grid_res=args.grid_res,
-                          skip_empty=grid is not None)
-        loss = ngp_loss(out, target, reg=args.reg)
-        loss.backward()
-        opt.step()
+    for step in range(1 + (graphed.steps_run if graphed else 0), args.steps + 1):
+        if graphed:
+            load()
+            loss = graphed()
+        else:
+            rays_o, rays_d, target = buf.next_batch(args.rays)
+            opt.zero_grad(set_to_none=False)
+            out = render_rays(model, rays_o, rays_d, NEAR, FAR, n_samples, density_grid=grid, grid_res=args.grid_res,
+                              skip_empty=grid is not None)
+            loss = ngp_loss(out, target, reg=args.reg)
+            loss.backward()
+            opt.step()
         window += loss.detach()
         window_n += 1
         if step % args.grid_every == 0 or step == args.steps:
@@ -99,6 +128,8 @@ def main():
             else:
                 cosine.step()
             grid = get_density_grid(model, dev, args.grid_res)
+            if graphed:
+                s_grid.copy_(grid)
             img = render_image(model, held_o, held_d, NEAR, FAR, n_samples=n_samples, grid_res=args.grid_res,
                                density_grid=grid, skip_empty=True)
             print("[step %d] loss %.5f | held-out psnr %.2f dB | grid %.1f %% occupied | lr %.2e | %.2f s" %

@@ -122,4 +122,15 @@ __device__ __forceinline__ void sincos_octaves(float xf, float (&sn)[L], float (
     }
 }
 
+// Clears n 32-bit words.  A kernel of the library's own rather than hipMemsetAsync: captured into a HIP graph, the
+// runtime's memset node stopped clearing once the device had been synchronised and other kernels launched between two
+// replays (observed on ROCm 7.2; tests/test_gpu_graph.py has the sequence).  The queue counters of the table-gradient
+// scatter then kept their old values: every queue looked full, the reduce pass added the previous replay's records
+// again -- table gradients off by 90 % -- and a replay took 2-20 ms instead of 0.6.  A kernel node carries its own
+// arguments.
+__global__ void zero_words_kernel(unsigned* __restrict__ p, int n);
+inline void launch_zero_words(void* p, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<unsigned*>(p), n);
+}
+
 }  // namespace nerf

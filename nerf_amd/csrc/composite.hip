@@ -530,9 +530,8 @@ extern "C" int nerf_occupancy_compact(const float* pts, int64_t P, const uint8_t
                                       float* pts_kept, float* dirs_kept, int32_t* count, void* stream) {
     NERF_REQUIRE(count, "nerf_occupancy_compact: null count");
     if (P == 0) {
-        if (hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
-            return fail(NERF_ELAUNCH, "nerf_occupancy_compact: cannot clear the count");
-        return NERF_OK;
+        launch_zero_words(count, 1, (hipStream_t)stream);
+        return check_launch("nerf_occupancy_compact(clear)");
     }
     NERF_REQUIRE(pts && grid && workspace && kept && slot && pts_kept, "nerf_occupancy_compact: null pointer");
     NERF_REQUIRE(P > 0 && P < (1ll << 31) && grid_cells >= 1 && grid_res >= 1, "nerf_occupancy_compact: P=%lld cells=%lld res=%d",

@@ -664,8 +664,8 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
                                      (int)((BIN_SEG_ROWS + 2) * 2 * sizeof(double)))) return rc;
         unsigned* counters = reinterpret_cast<unsigned*>(workspace);
         float4* queues = reinterpret_cast<float4*>(reinterpret_cast<char*>(workspace) + BIN_COUNTER_BYTES);
-        if (hipMemsetAsync(counters, 0, BIN_COUNTER_BYTES, stream) != hipSuccess)
-            return fail(NERF_ELAUNCH, "hashgrid_scatter: cannot clear the queue counters");
+        launch_zero_words(counters, (int)(BIN_COUNTER_BYTES / 4), stream);
+        if (int rc = check_launch("hashgrid_scatter(clear)")) return rc;
         hipLaunchKernelGGL(hashgrid_bin_kernel, dim3((unsigned)ceil_div(P, BIN_PTS)), dim3(BIN_PTS), 0, stream, x, P, d_enc,
                            levels, level_stride, bl, counters, queues);
         if (int rc = check_launch("hashgrid_scatter(bin)")) return rc;

@@ -53,7 +53,9 @@ class RayBuffer:
         return ops.raygen_multi(self.cams, self.H, self.W, cam_id.to(self.device), pix.to(self.device), self.images)
 
     def _reshuffle(self):
-        self._order = torch.randperm(self.total, generator=self.gen)
+        # drawn on the host (the same order on every rank, whatever its GPU) and kept on the device: one copy per epoch;
+        # a batch is then cut and split into (image, pixel) on the device, with no host-to-device copy per step
+        self._order = torch.randperm(self.total, generator=self.gen).to(self.device)
         self._pos = 0
 
     def next_batch(self, rays: int):
@@ -65,6 +67,6 @@ class RayBuffer:
         flat = self._order[self._pos + self.rank * rays: self._pos + (self.rank + 1) * rays]
         self._pos += span
         hw = self.H * self.W
-        cam_id = torch.div(flat, hw, rounding_mode="floor").to(torch.int32)
-        pix = (flat % hw).to(torch.int32)
-        return self.rays_of(cam_id, pix)
+        cam_id = torch.div(flat, hw, rounding_mode="floor")
+        pix = flat - cam_id * hw
+        return self.rays_of(cam_id.to(torch.int32), pix.to(torch.int32))

@@ -37,6 +37,9 @@ class GraphedStep:
     def __init__(self, step: Callable[[], object], warmup: int = 3, optimizers=(), prepare=None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs a GPU")
+        # The graph holds the ADDRESSES of everything the step read: the step function is kept, and with it the tensors
+        # its closure owns.  (Dropped, they go back to the allocator, whose next client overwrites what the replays read.)
+        self.step = step
         self.optimizers = list(optimizers)
         for opt in self.optimizers:
             if not all(g.get("capturable", False) for g in opt.param_groups):

@@ -88,3 +88,46 @@ def test_graphed_hash_grid_step_matches_eager_steps(dev):
         assert abs(a - b) < 1e-4 * max(1.0, abs(a)), (losses_a, losses_g)
     for (n, a), b, c in zip(m_a.named_parameters(), m_b.parameters(), m_g.parameters()):
         assert rel_l2(a, c) <= max(5.0 * rel_l2(a, b), 2e-3), (n, rel_l2(a, c), rel_l2(a, b))
+
+
+def test_replays_are_unaffected_by_kernels_and_allocations_between_them(dev):
+    """A training loop copies new data in, draws numbers and logs between replays.  131,072 points: the size at which
+    the table gradients go through the binned scatter, whose queue counters must be cleared by every replay (a
+    captured ``hipMemsetAsync`` stopped doing so once other kernels had run between two replays: queues looked full,
+    the reduce pass added the previous replay's records again).  With a learning rate of zero every replay computes
+    the same gradients; float atomics leave their order open, hence 1e-5."""
+    import gc
+
+    from nerf_amd.graph import GraphedStep
+    from nerf_amd.render import train_step
+    def build():   # the step's inputs are locals of this call: only the GraphedStep keeps them (and the step function) alive
+        model, buckets, opt, o, d, u, gt, z_lin = _ngp_setup(dev, rays=4096, capturable=True)
+        for group in opt.param_groups:
+            group["lr"] = 0.0
+
+        def step():
+            loss = train_step(model, o, d, gt, 0.05, 1.2, 32, buckets=buckets, t_rand=u, z_lin=z_lin, white_bkgd=False)
+            opt.step()
+            return loss
+
+        loss_eager = float(step())   # the reference: the same step issued launch by launch
+        grads_eager = [f.clone() for f in buckets.flats]
+        return GraphedStep(step, warmup=2, optimizers=[opt]), buckets, loss_eager, grads_eager
+
+    g, buckets, loss_ref, ref = build()
+    gc.collect()
+    assert all(float(r.abs().max()) > 0 for r in ref)
+    for _ in range(40):
+        g()
+    for it in range(3):
+        torch.cuda.synchronize()   # (as a loop that times or logs does; the stale state needed one)
+        junk = [torch.full((1 << 18,), 7.0 + it, device=dev) for _ in range(8)]     # new blocks, written
+        noise = torch.rand(4096, 64, device=dev)
+        copy = noise.clone().mul_(2.0)
+        del junk
+        for again in range(3):   # (the stale state showed from the second replay on)
+            loss = float(g())
+            assert abs(loss - loss_ref) <= 1e-6 * max(1.0, abs(loss_ref)), (it, again, loss, loss_ref)
+            for f, r in zip(buckets.flats, ref):
+                assert float((f - r).norm()) <= 1e-5 * float(r.norm()), (it, again, float((f - r).norm() / r.norm()))
+        del noise, copy
