@@ -22,6 +22,7 @@ python3 tools/summarize_pmc.py "$OUT"/mfma/*/*_counter_collection.csv "$OUT"/fet
 python3 tools/summarize_pmc.py "$OUT"/kfetch/*/*_counter_collection.csv "$OUT"/kwrite/*/*_counter_collection.csv > "$OUT/bench_kernels_pmc_summary.txt"
 ls "$OUT"
 python3 tools/make_traffic_json.py "$OUT" > "$OUT/roofline_traffic.json"
+cp "$OUT/roofline_traffic.json" profiles/roofline_traffic.json   # what the bench run below reports as roofline.traffic
 # the bandwidth-bound stages through the C ABI (the table of achieved GB/s per stage)
 timeout -s KILL 240 python3 bench_kernels.py > "$OUT/bench_kernels.jsonl" 2> "$OUT/bench_kernels.err"
 timeout -s KILL 240 python3 bench.py --steps 20 --warmup 3 > "$OUT/bench.log" 2>&1
