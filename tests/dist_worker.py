@@ -104,6 +104,20 @@ def main():
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     result["params_identical_on_all_ranks"] = bool(flag.item() == 1.0)
     result["params_moved"] = True
+    # inference: the image's rows split over the ranks and gathered (the path's only collective), against the whole
+    # image rendered by one process.  37 rows: the shares are ragged.
+    from nerf_amd.Camera import Camera, look_at_camera
+    eye = torch.tensor([3.2, 1.8, 1.7]) * scale
+    cam = Camera(None, None, (40.0, 41.0), 37, 24, c2w=look_at_camera(eye, 2 * eye, torch.tensor([0.0, 0.0, 1.0])).to(dev))
+    img_o, img_d = cam.get_rays()
+    ikw = dict(n_samples=32, return_depth=True)
+    if kind == "vanilla":
+        ikw.update(white_bkgd=True, fine_model=models[1], n_importance=48)
+    img, dep = render.render_image_sharded(models[0], img_o, img_d, near, far, **ikw)
+    if rank == 0:
+        whole, whole_dep = render.render_image(models[0], img_o, img_d, near, far, **ikw)
+        result["sharded_image_equal"] = bool(torch.equal(img, whole) and torch.equal(dep, whole_dep))
+        result["sharded_image_shape"] = list(img.shape)
     if rank == 0:
         torch.save(result, out_path)
     dist.barrier()

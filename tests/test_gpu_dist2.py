@@ -43,6 +43,7 @@ def test_two_rank_step_equals_the_whole_batch_step(dev, tmp_path, kind):
     res = _run_two_ranks(kind, tmp_path)
     assert abs(res["dp_loss"] - res["full_loss"]) < 1e-6 * max(1.0, abs(res["full_loss"]))
     assert res["params_identical_on_all_ranks"]
+    assert res["sharded_image_shape"] == [37, 24, 3] and res["sharded_image_equal"]   # row-sharded inference = one process
     assert sorted(res["send_order"]) == [0, 1] and res["send_order"][0] == 0   # fine model / tables first
     worst = 0.0
     for n, g_full in res["full_grads"].items():
