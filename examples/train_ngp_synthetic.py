@@ -21,10 +21,11 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from nerf_amd.Camera import Camera  # noqa: E402
 from nerf_amd.data.ray_buffer import RayBuffer  # noqa: E402
+from nerf_amd.dist import GradBuckets  # noqa: E402
 from nerf_amd.models.FastNGPNeRF import FastNGPNeRF  # noqa: E402
 from nerf_amd.optim import FusedAdam  # noqa: E402
 from nerf_amd.graph import GraphedStep  # noqa: E402
-from nerf_amd.render import get_density_grid, ngp_loss, psnr, render_image, render_rays, train_step  # noqa: E402
+from nerf_amd.render import get_density_grid, ngp_loss, psnr, render_image, train_step  # noqa: E402
 from nerf_amd.utils.get_rays import evaluate_fake_radiance_field_complex  # noqa: E402
 
 SHRINK = 2.5            # the field's torus (radius 1.3 overall) fits the unit cube at 1 / 2.5
@@ -75,7 +76,12 @@ def main():
     held_o, held_d = held_cam.get_rays()
 
     model = FastNGPNeRF().to(dev)
-    opt = FusedAdam(model.parameters(), lr=1e-2, eps=1e-15, capturable=args.graph)
+    # gradients land in two flat buffers (tables, everything else) instead of one tensor per parameter: two fills per
+    # step instead of 25, no per-parameter accumulation kernels, and on several GPUs the buffers are what is all-reduced
+    buckets = GradBuckets([list(model.hash_encoder.parameters()),
+                           [p for n, p in model.named_parameters() if not n.startswith("hash_encoder")]])
+    opt = FusedAdam(buckets.parameters(), lr=1e-2, eps=1e-15, capturable=args.graph)
+    loss_fn = lambda out, t: ngp_loss(out, t, reg=args.reg)   # noqa: E731
     plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=2)
     cosine = None
     grid = None
@@ -93,9 +99,8 @@ def main():
             s_o.copy_(o), s_d.copy_(d), s_t.copy_(t), s_u.uniform_()
 
         def captured():
-            opt.zero_grad(set_to_none=False)
-            loss = train_step(model, s_o, s_d, s_t, NEAR, FAR, n_samples, loss_fn=lambda out, t: ngp_loss(out, t, reg=args.reg),
-                              t_rand=s_u, z_lin=z_lin, density_grid=s_grid, grid_res=args.grid_res)
+            loss = train_step(model, s_o, s_d, s_t, NEAR, FAR, n_samples, loss_fn=loss_fn, buckets=buckets, t_rand=s_u,
+                              z_lin=z_lin, density_grid=s_grid, grid_res=args.grid_res)
             opt.step()
             return loss
 
@@ -108,11 +113,8 @@ def main():
             loss = graphed()
         else:
             rays_o, rays_d, target = buf.next_batch(args.rays)
-            opt.zero_grad(set_to_none=False)
-            out = render_rays(model, rays_o, rays_d, NEAR, FAR, n_samples, density_grid=grid, grid_res=args.grid_res,
-                              skip_empty=grid is not None)
-            loss = ngp_loss(out, target, reg=args.reg)
-            loss.backward()
+            loss = train_step(model, rays_o, rays_d, target, NEAR, FAR, n_samples, loss_fn=loss_fn, buckets=buckets,
+                              density_grid=grid, grid_res=args.grid_res, skip_empty=grid is not None)
             opt.step()
         window += loss.detach()
         window_n += 1
