@@ -124,3 +124,36 @@ def test_vanilla_hierarchical_render_skipping_equals_masking(dev):
         img[skip] = render_image(coarse, o.view(20, 20, 3), d.view(20, 20, 3), 0.05, 1.8, 64, grid_res=32, density_grid=grid,
                                  fine_model=fine, n_importance=64, rays_per_tile=150, return_depth=True, skip_empty=skip)
     assert torch.equal(img[True][0], img[False][0]) and torch.equal(img[True][1], img[False][1])
+
+
+@pytest.mark.parametrize("kind", ["ngp", "vanilla"])
+def test_render_with_nothing_occupied(dev, kind):
+    """An empty grid keeps no sample: the model runs on zero points, the render is the background and the step still
+    goes through (the reference's masked render of the same grid gives the same picture)."""
+    from nerf_amd.render import nerf_loss, render_image, render_rays
+    if kind == "ngp":
+        m, fine, kw = _ngp_with_structure(dev), None, {}
+    else:
+        from nerf_amd.models.NeRF import NeRF
+        torch.manual_seed(0)
+        m, fine = NeRF().to(dev), NeRF().to(dev)
+        kw = dict(fine_model=fine, n_importance=16, white_bkgd=True)
+    o, d = _rays(12, dev)
+    grid = torch.zeros(32 ** 3, dtype=torch.uint8, device=dev)
+    u = torch.rand(o.shape[0], 24, generator=torch.Generator().manual_seed(1)).to(dev)
+    outs = {}
+    for skip in (False, True):
+        for p in list(m.parameters()) + (list(fine.parameters()) if fine else []):
+            p.grad = None
+        out = render_rays(m, o, d, 0.05, 1.8, 24, t_rand=u, density_grid=grid, grid_res=32, skip_empty=skip, **kw)
+        nerf_loss(out, torch.rand(o.shape[0], 3, generator=torch.Generator().manual_seed(2)).to(dev)).backward()
+        outs[skip] = out
+        for p in m.parameters():
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+    background = 1.0 if kind == "vanilla" else 0.0
+    for key in ("rgb", "weights", "depth") + (("rgb_fine",) if fine else ()):
+        assert torch.equal(outs[True][key], outs[False][key]), key
+    assert float((outs[True]["rgb"].detach() - background).abs().max()) == 0.0 and float(outs[True]["weights"].detach().abs().max()) == 0.0
+    img = render_image(m, o.view(12, 12, 3), d.view(12, 12, 3), 0.05, 1.8, n_samples=24, grid_res=32, density_grid=grid,
+                       skip_empty=True, white_bkgd=(kind == "vanilla"))
+    assert float((img - background).abs().max()) == 0.0
