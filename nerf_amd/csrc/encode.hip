@@ -155,12 +155,21 @@ __global__ void hashgrid_bwd_kernel(const float* __restrict__ x, int64_t P, cons
 // The copy is double: LDS float atomics are executed lane by lane on this chip, double ones are not.
 constexpr int HG_LDS_THREADS = 1024;
 constexpr unsigned HG_LDS_MAX_ROWS = 8192;   // 128 KiB of LDS
+constexpr int HG_LDS_MAX_LEVELS = 8;
+struct LdsLevels {   // the levels of one launch: blockIdx.y picks one (at 262,144 points a level by itself fills half the chip)
+    float* table[HG_LDS_MAX_LEVELS];
+    int res[HG_LDS_MAX_LEVELS];
+    unsigned size[HG_LDS_MAX_LEVELS];
+    int id[HG_LDS_MAX_LEVELS];   // position of the level in the encoding
+};
 __global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const float* __restrict__ x, int64_t P,
-                                                                          const float* __restrict__ d_out, float* tab,
-                                                                          int res, unsigned size, int l, int levels,
-                                                                          int64_t level_stride) {
+                                                                          const float* __restrict__ d_out, LdsLevels lv,
+                                                                          int levels, int64_t level_stride) {
     extern __shared__ double s_tab[];   // [2][size]: feature-major (two atomics on the adjacent doubles of a row collide)
     const int tid = threadIdx.x;
+    float* tab = lv.table[blockIdx.y];
+    const int res = lv.res[blockIdx.y], l = lv.id[blockIdx.y];
+    const unsigned size = lv.size[blockIdx.y];
     for (unsigned i = tid; i < 2 * size; i += HG_LDS_THREADS) s_tab[i] = 0.0;
     __syncthreads();
     const int64_t per = (P + gridDim.x - 1) / gridDim.x;
@@ -620,6 +629,18 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
     if (binned && (size_t)workspace % 16)
         return fail(NERF_EINVAL, "hashgrid_scatter: the workspace must be 16-byte aligned (128 for whole-line writes)");
     HashGradLevels lv;
+    LdsLevels ll;
+    int n_lds = 0;
+    unsigned lds_rows = 0;
+    auto flush_lds_levels = [&]() -> int {   // one launch for the LDS-resident levels collected so far
+        if (n_lds == 0) return NERF_OK;
+        const int blocks = (int)(P / 2048 < 256 ? P / 2048 : 256);
+        hipLaunchKernelGGL(hashgrid_bwd_lds_kernel, dim3(blocks, n_lds), dim3(HG_LDS_THREADS), (size_t)lds_rows * 2 * sizeof(double),
+                           stream, x, P, d_enc, ll, levels, level_stride);
+        n_lds = 0;
+        lds_rows = 0;
+        return check_launch("hashgrid_scatter(lds)");
+    };
     BinLevels bl;
     bl.n = 0;
     bl.cnt_first[0] = bl.wg_first[0] = 0;
@@ -629,10 +650,14 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
         if (res[l] < 1 || sizes[l] < 1) return fail(NERF_EINVAL, "hashgrid: level %d has res=%d size=%d", l, res[l], sizes[l]);
         if ((unsigned)sizes[l] <= HG_LDS_MAX_ROWS && P >= 65536) {
             // enough points per workgroup to pay for adding the whole table once per workgroup
-            const int blocks = (int)(P / 2048 < 256 ? P / 2048 : 256);
-            hipLaunchKernelGGL(hashgrid_bwd_lds_kernel, dim3(blocks), dim3(HG_LDS_THREADS), (size_t)sizes[l] * 2 * sizeof(double),
-                               stream, x, P, d_enc, d_tables[l], res[l], (unsigned)sizes[l], l, levels, level_stride);
-            if (int rc = check_launch("hashgrid_scatter(lds)")) return rc;
+            if (n_lds == HG_LDS_MAX_LEVELS)
+                if (int rc = flush_lds_levels()) return rc;
+            ll.table[n_lds] = d_tables[l];
+            ll.res[n_lds] = res[l];
+            ll.size[n_lds] = (unsigned)sizes[l];
+            ll.id[n_lds] = l;
+            lds_rows = lds_rows > (unsigned)sizes[l] ? lds_rows : (unsigned)sizes[l];
+            ++n_lds;
         } else if (binned && level_is_binned(sizes[l])) {
             const BinPlan pl = bin_plan(P, sizes[l]);
             const int j = bl.n++;
@@ -658,6 +683,7 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
             ++big;
         }
     }
+    if (int rc = flush_lds_levels()) return rc;
     if (bl.n) {
         if ((size_t)bl.cnt_first[bl.n] * 4 > BIN_COUNTER_BYTES) return fail(NERF_EINVAL, "hashgrid_scatter: too many queues");
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hashgrid_reduce_kernel), red_enabled,
