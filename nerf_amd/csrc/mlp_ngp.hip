@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void ngp_bwd_fused_kernel(const float* __re
 // d2[hd 0..31], d2[hd 32..63], d1[0], d1[1]), register (e / 64) % 16, lane e % 64 = (column i, half s), i.e. row
 // rowmap(register, s) of the tile; then the bias sums per lane.  One thread per element and 16th of the slots, plain
 // additions in a fixed order: the same bits from run to run.
-constexpr int RED_E = 64, RED_G = 16;
+constexpr int RED_E = 64, RED_G = 16;   // (a row of 64 bias sums must be one block's elements)
 __global__ __launch_bounds__(RED_E * RED_G) void ngp_wgrad_reduce_kernel(const float* __restrict__ partials, int slots, NgpGrads g) {
     __shared__ float s_sum[RED_G][RED_E];
     const int el = threadIdx.x % RED_E, grp = threadIdx.x / RED_E;
