@@ -289,6 +289,23 @@ def gpu_main(args):
                                                      "grid (a ball of occupied cells keeping %.2f of the samples) are dropped before the model: "
                                                      "same render as zeroing their densities" % (args.occupancy or 0.2),
                                          "rays_per_gpu": rays, "final_loss": loss3, **info3}}
+        # ... and both at the data-parallel batch, where the step is bound by the GPU and not by its 25 launches
+        if world == 1 and rays < 65536:
+            del step3
+            torch.cuda.empty_cache()
+            big = 65536
+            step4, _, info4 = build_ngp_step(rank, big, dev, None, world, (not args.no_graph))
+            dt4, _ = timed_steps(step4, 5, 2, world, dev)
+            del step4
+            torch.cuda.empty_cache()
+            step5, _, info5 = build_ngp_step(rank, big, dev, None, world, False, occupancy=args.occupancy or 0.2)
+            dt5, _ = timed_steps(step5, 5, 2, world, dev)
+            del step5
+            torch.cuda.empty_cache()
+            secondary_skip["at_65536_rays"] = {"ms_per_step_all_samples": 1e3 * dt4 / 5, "rays_per_s_all_samples": big * 5 / dt4,
+                                               "ms_per_step_empty_skipped": 1e3 * dt5 / 5, "rays_per_s_empty_skipped": big * 5 / dt5,
+                                               "samples_kept": info5.get("samples_kept"), "steps": 5,
+                                               "note": "the same two steps at 65,536 rays per GPU (the data-parallel batch)"}
 
     result = None
     if rank == 0 and args.model == "ngp":
