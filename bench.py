@@ -104,7 +104,7 @@ def grid_keeping(fraction, pts, dev):
     return grid, {"grid_cells_occupied": cells, "samples_kept": kept, "ball_radius": hi}
 
 
-def build_step(kind, rank, rays, dev, chunk_rays, capturable=False, occupancy=None):
+def build_step(kind, rank, rays, dev, chunk_rays, capturable=False, occupancy=None, skip_mode=True):
     """One training step of the vanilla (coarse + fine 8x256 MLPs, 64 + 128 samples) or hash-grid workload:
     fused ray generation + stratified sampling, chunked forward/backward with the gradients in flat buckets
     (their cross-rank sum starts under the last chunk's backward), fused Adam.  Returns (step, model)."""
@@ -131,7 +131,7 @@ def build_step(kind, rank, rays, dev, chunk_rays, capturable=False, occupancy=No
         if occupancy:
             pts0 = ops.raygen_sample(c2w, FOCAL, FOCAL, W * 0.5, H * 0.5, H, W, pix, z_lin, u_c)[3]
             grid, occ_info = grid_keeping(occupancy, pts0, dev)
-            kw.update(density_grid=grid, grid_res=32, skip_empty=True)
+            kw.update(density_grid=grid, grid_res=32, skip_empty=skip_mode)
     else:
         from nerf_amd.models.NeRF import NeRF
         torch.manual_seed(0)
@@ -186,9 +186,21 @@ def build_ngp_step(rank, rays, dev, chunk_rays, world, use_graph, occupancy=None
     """The hash-grid step; with use_graph captured into a HIP graph and replayed where that applies: one GPU (no
     collective inside the step) and one ray chunk.  Returns (step, model, info for the result's config).
     occupancy: the step skips the samples in empty cells of a synthetic occupancy grid (a ball of occupied cells, sized
-    so that about this fraction of the batch's samples is kept); sizes then depend on the data: the step is issued launch
-    by launch, never from a graph."""
+    so that about this fraction of the batch's samples is kept).  Replayed from a graph, the number of kept samples stays
+    on the device and every tensor keeps its full size; issued launch by launch (--no-graph, several GPUs, ray chunks) the
+    count is read back and the tensors shrink to it."""
     if occupancy:
+        single = world == 1 and (chunk_rays is None or chunk_rays >= rays) and rays <= 65536
+        if use_graph and single:
+            # the number of kept samples stays in device memory (skip_empty="device"): fixed sizes, nothing read back
+            try:
+                from nerf_amd.graph import GraphedStep
+                eager, model = build_step("ngp", rank, rays, dev, chunk_rays, capturable=True, occupancy=occupancy, skip_mode="device")
+                graphed = GraphedStep(eager, warmup=3, optimizers=[eager.opt])
+                graphed.buckets = eager.buckets
+                return graphed, model, {"hip_graph": True, "skip_empty": "device", **eager.occupancy}
+            except Exception as e:   # the same kernels run eagerly; the line says so
+                print("hip graph capture of the skipping step failed, running eagerly: %r" % (e,), file=sys.stderr)
         step, model = build_step("ngp", rank, rays, dev, chunk_rays, occupancy=occupancy)
         return step, model, {"hip_graph": False, "skip_empty": True, **step.occupancy}
     if use_graph and world == 1 and (chunk_rays is None or chunk_rays >= rays) and rays <= 65536:
@@ -279,7 +291,7 @@ def gpu_main(args):
         # the same step skipping the samples in empty cells of a synthetic occupancy grid (a third result, beside the others)
         del step2, ngp
         torch.cuda.empty_cache()
-        step3, _, info3 = build_ngp_step(rank, rays, dev, chunk, world, False, occupancy=args.occupancy or 0.2)
+        step3, _, info3 = build_ngp_step(rank, rays, dev, chunk, world, (not args.no_graph), occupancy=args.occupancy or 0.2)
         dt3, loss3 = timed_steps(step3, n2, 3, world, dev)
         if rank == 0:
             secondary_skip = {"metric": "rays/sec fwd+bwd (hash-grid model, 64 samples, empty samples skipped)",
@@ -298,13 +310,13 @@ def gpu_main(args):
             dt4, _ = timed_steps(step4, 5, 2, world, dev)
             del step4
             torch.cuda.empty_cache()
-            step5, _, info5 = build_ngp_step(rank, big, dev, None, world, False, occupancy=args.occupancy or 0.2)
+            step5, _, info5 = build_ngp_step(rank, big, dev, None, world, (not args.no_graph), occupancy=args.occupancy or 0.2)
             dt5, _ = timed_steps(step5, 5, 2, world, dev)
             del step5
             torch.cuda.empty_cache()
             secondary_skip["at_65536_rays"] = {"ms_per_step_all_samples": 1e3 * dt4 / 5, "rays_per_s_all_samples": big * 5 / dt4,
                                                "ms_per_step_empty_skipped": 1e3 * dt5 / 5, "rays_per_s_empty_skipped": big * 5 / dt5,
-                                               "samples_kept": info5.get("samples_kept"), "steps": 5,
+                                               "samples_kept": info5.get("samples_kept"), "steps": 5, "hip_graph": info5.get("hip_graph"),
                                                "note": "the same two steps at 65,536 rays per GPU (the data-parallel batch)"}
 
     result = None

@@ -6,9 +6,8 @@ ReduceLROnPlateau handing over to CosineAnnealingLR, an occupancy grid refreshed
 once the grid exists -- the samples in its empty cells skipped.
 
     python examples/train_ngp_synthetic.py --steps 1500
-    python examples/train_ngp_synthetic.py --steps 1500 --graph    # the step replayed from a HIP graph (densities in
-                                                                   # empty cells zeroed instead of their samples skipped:
-                                                                   # a captured step's sizes cannot depend on the data)
+    python examples/train_ngp_synthetic.py --steps 1500 --graph    # the step replayed from a HIP graph: the number of
+                                                                   # samples that survive the grid stays on the device
 """
 import argparse
 import math
@@ -100,7 +99,7 @@ def main():
 
         def captured():
             loss = train_step(model, s_o, s_d, s_t, NEAR, FAR, n_samples, loss_fn=loss_fn, buckets=buckets, t_rand=s_u,
-                              z_lin=z_lin, density_grid=s_grid, grid_res=args.grid_res)
+                              z_lin=z_lin, density_grid=s_grid, grid_res=args.grid_res, skip_empty="device")
             opt.step()
             return loss
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NERF_ABI_VERSION 3
+#define NERF_ABI_VERSION 4
 #define NERF_OK 0
 #define NERF_EINVAL (-22) /* bad argument (shape, null pointer, unsupported size) */
 #define NERF_ELAUNCH (-5) /* the HIP runtime rejected a launch                    */
@@ -191,6 +191,11 @@ int nerf_expand_kept(const float* rgb_kept, const float* sigma_kept, const int32
                      float* rgb, float* sigma, void* stream);
 int nerf_gather_kept(const float* d_rgb, const float* d_sigma, const int32_t* kept, int64_t K,
                      float* d_rgb_kept, float* d_sigma_kept, void* stream);
+/* The same for a caller that leaves the count on the device (no read-back: the step can then be captured
+ * into a HIP graph): sample p hands its gradient to position slot[p] of d_rgb_kept [P,3] / d_sigma_kept [P]
+ * (entries behind the count stay untouched). */
+int nerf_gather_kept_by_slot(const float* d_rgb, const float* d_sigma, const int32_t* slot, int64_t P,
+                             float* d_rgb_kept, float* d_sigma_kept, void* stream);
 
 /* ---------------------------------------------------------- fused MLPs ---- */
 
@@ -285,6 +290,21 @@ int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, i
                      const float* sigma, float* ws, float* ws2, float* const* d_tables,
                      float* const* grads, void* scatter_ws, size_t scatter_ws_bytes, int phases,
                      void* stream);
+/* The two calls above on the first *count points of arrays sized for P_max, count being one int32 in
+ * device memory (nerf_occupancy_compact's): the model on the samples that survive the occupancy grid
+ * (src/train_nerf_ngp.py:113-117 evaluates all of them) without the host ever learning how many they are.
+ * Every buffer, workspace and size query is that of P_max points; grids are launched for P_max and the
+ * workgroups behind the count leave at once; outputs behind the count are not written, inputs there not
+ * read.  count > P_max is taken as P_max, count <= 0 as nothing to do. */
+int nerf_mlp_ngp_fwd_counted(const float* x, const float* dirs, int dirs_div, int64_t P_max,
+                             const int32_t* count, const float* const* tables, const int* res,
+                             const int* sizes, const float* packed, float* rgb, float* sigma,
+                             float* ws, float* enc, void* stream);
+int nerf_mlp_ngp_bwd_counted(const float* x, const float* d_rgb, const float* d_sigma, int64_t P_max,
+                             const int32_t* count, const int* res, const int* sizes,
+                             const float* packed, const float* rgb, const float* sigma, float* ws,
+                             float* ws2, float* const* d_tables, float* const* grads,
+                             void* scatter_ws, size_t scatter_ws_bytes, int phases, void* stream);
 
 /* One Adam step over `count` tensors in one launch: torch.optim.Adam (no amsgrad), the optimiser
  * of the reference's training loops (src/train_nerf_llff.py:82 and src/train_nerf_skow.py:47: lr 5e-4,

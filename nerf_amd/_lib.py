@@ -40,6 +40,7 @@ SIGNATURES = {
     "nerf_occupancy_compact": (_I, [_P, _L, _P, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_expand_kept": (_I, [_P, _P, _P, _L, _P, _P, _P]),
     "nerf_gather_kept": (_I, [_P, _P, _P, _L, _P, _P, _P]),
+    "nerf_gather_kept_by_slot": (_I, [_P, _P, _P, _L, _P, _P, _P]),
     "nerf_mlp_vanilla_pack_floats": (C.c_size_t, []),
     "nerf_mlp_vanilla_pack": (_I, [_P, _I, _P, _P]),
     "nerf_mlp_vanilla_ws_floats_per_point": (C.c_size_t, []),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "nerf_mlp_ngp_pack": (_I, [_P, _P, _P]),
     "nerf_mlp_ngp_fwd": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nerf_mlp_ngp_bwd": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I, _P]),
+    "nerf_mlp_ngp_fwd_counted": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nerf_mlp_ngp_bwd_counted": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I, _P]),
     "nerf_render_loss_workspace_floats": (C.c_size_t, [_L]),
     "nerf_render_loss_fwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "nerf_render_loss_bwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),

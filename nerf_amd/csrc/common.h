@@ -122,6 +122,15 @@ __device__ __forceinline__ void sincos_octaves(float xf, float (&sn)[L], float (
     }
 }
 
+// The number of points a kernel works on: P, or the count in device memory when the caller passes one (a step whose
+// sizes depend on the data -- samples skipped by occupancy -- launched with the host's upper bound P and no read-back,
+// so that it can be captured into a HIP graph).
+__device__ __forceinline__ int64_t points_in_use(int64_t P, const int* __restrict__ count) {
+    if (!count) return P;
+    const int64_t c = *count;
+    return c < P ? (c > 0 ? c : 0) : P;
+}
+
 // Clears n 32-bit words.  A kernel of the library's own rather than hipMemsetAsync: captured into a HIP graph, the
 // runtime's memset node stopped clearing once the device had been synchronised and other kernels launched between two
 // replays (observed on ROCm 7.2; tests/test_gpu_graph.py has the sequence).  The queue counters of the table-gradient

@@ -360,6 +360,19 @@ __global__ __launch_bounds__(256) void gather_kept_kernel(const float* __restric
     for (int c = 0; c < 3; ++c) d_rgb_k[3 * k + c] = d_rgb ? d_rgb[3 * p + c] : 0.0f;
 }
 
+// The same from the samples' side, for a caller that does not know K on the host: sample p hands its gradient to
+// position slot[p] (kept samples appear in their own order, so the writes of a wave are contiguous but for the gaps).
+__global__ __launch_bounds__(256) void gather_by_slot_kernel(const float* __restrict__ d_rgb, const float* __restrict__ d_sigma,
+                                                             const int32_t* __restrict__ slot, int64_t P,
+                                                             float* __restrict__ d_rgb_k, float* __restrict__ d_sigma_k) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int64_t k = slot[p];
+    if (k < 0) return;
+    d_sigma_k[k] = d_sigma ? d_sigma[p] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d_rgb_k[3 * k + c] = d_rgb ? d_rgb[3 * p + c] : 0.0f;
+}
 
 // ---------------------------------------------------------------------------
 // The training loss of the reference's loops and its gradient, one pass each:
@@ -565,6 +578,16 @@ extern "C" int nerf_gather_kept(const float* d_rgb, const float* d_sigma, const 
     hipLaunchKernelGGL(gather_kept_kernel, dim3((unsigned)ceil_div(K, 256)), dim3(256), 0, (hipStream_t)stream, d_rgb, d_sigma,
                        kept, K, d_rgb_kept, d_sigma_kept);
     return check_launch("nerf_gather_kept");
+}
+
+extern "C" int nerf_gather_kept_by_slot(const float* d_rgb, const float* d_sigma, const int32_t* slot, int64_t P,
+                                        float* d_rgb_kept, float* d_sigma_kept, void* stream) {
+    if (P == 0) return NERF_OK;
+    NERF_REQUIRE(slot && d_rgb_kept && d_sigma_kept, "nerf_gather_kept_by_slot: null pointer");
+    NERF_REQUIRE(P > 0, "nerf_gather_kept_by_slot: P=%lld", (long long)P);
+    hipLaunchKernelGGL(gather_by_slot_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream, d_rgb, d_sigma,
+                       slot, P, d_rgb_kept, d_sigma_kept);
+    return check_launch("nerf_gather_kept_by_slot");
 }
 
 extern "C" size_t nerf_render_loss_workspace_floats(int64_t R) { return R > 0 ? 3 * (size_t)loss_blocks(R) : 0; }

@@ -102,12 +102,12 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(const float* __restri
 template <bool LEVEL_MAJOR>
 __global__ __launch_bounds__(256) void hashgrid_fwd_pinned_kernel(const float* __restrict__ x, int64_t P, HashLevels lv,
                                                                   int levels, int nblk, float* __restrict__ out,
-                                                                  int64_t level_stride) {
+                                                                  int64_t level_stride, const int* __restrict__ count) {
     const int g = blockIdx.x & 7, i = blockIdx.x >> 3;
     const int l = g + 8 * (i / nblk);
     if (l >= levels) return;
     const int64_t p = (int64_t)(i % nblk) * 256 + threadIdx.x;
-    if (p >= P) return;
+    if (p >= points_in_use(P, count)) return;
     const Cell c = locate(x, p, lv.res[l]);
     float2 f[8];
     gather_corners(lv.table[l], c, lv.size[l], f);
@@ -129,11 +129,11 @@ __device__ __forceinline__ int64_t denc_index(int64_t p, int l, int levels, int6
 }
 
 __global__ void hashgrid_bwd_kernel(const float* __restrict__ x, int64_t P, const float* __restrict__ d_out,
-                                    HashGradLevels lv, int levels, int64_t level_stride) {
+                                    HashGradLevels lv, int levels, int64_t level_stride, const int* __restrict__ count) {
     const int j = blockIdx.y, l = lv.id[j];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t >> 2;
-    if (p >= P) return;
+    if (p >= points_in_use(P, count)) return;
     const int f = (int)t & 1, cx = ((int)t >> 1) & 1;
     const Cell c = locate(x, p, lv.res[j]);
     const float g = d_out[denc_index(p, l, levels, level_stride) + f];
@@ -162,11 +162,13 @@ struct LdsLevels {   // the levels of one launch: blockIdx.y picks one (at 262,1
     unsigned size[HG_LDS_MAX_LEVELS];
     int id[HG_LDS_MAX_LEVELS];   // position of the level in the encoding
 };
-__global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const float* __restrict__ x, int64_t P,
+__global__ __launch_bounds__(HG_LDS_THREADS) void hashgrid_bwd_lds_kernel(const float* __restrict__ x, int64_t P_max,
                                                                           const float* __restrict__ d_out, LdsLevels lv,
-                                                                          int levels, int64_t level_stride) {
+                                                                          int levels, int64_t level_stride,
+                                                                          const int* __restrict__ count) {
     extern __shared__ double s_tab[];   // [2][size]: feature-major (two atomics on the adjacent doubles of a row collide)
     const int tid = threadIdx.x;
+    const int64_t P = points_in_use(P_max, count);
     float* tab = lv.table[blockIdx.y];
     const int res = lv.res[blockIdx.y], l = lv.id[blockIdx.y];
     const unsigned size = lv.size[blockIdx.y];
@@ -274,10 +276,13 @@ __device__ __forceinline__ Cell locate3(const float (&xyz)[3], int res) {
     return c;
 }
 
-__global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* __restrict__ x, int64_t P,
+__global__ __launch_bounds__(BIN_PTS, 6) void hashgrid_bin_kernel(const float* __restrict__ x, int64_t P_max,
                                                                const float* __restrict__ d_out, int levels,
                                                                int64_t level_stride, BinLevels lv,
-                                                               unsigned* __restrict__ counters, float4* __restrict__ queues) {
+                                                               unsigned* __restrict__ counters, float4* __restrict__ queues,
+                                                               const int* __restrict__ count) {
+    const int64_t P = points_in_use(P_max, count);
+    if ((int64_t)blockIdx.x * BIN_PTS >= P) return;   // the whole workgroup (the grid covers P_max)
     // The kernel is bound by latency, not by a unit (vector ALU and LDS ~30 % busy each, waves waiting 60 % of their
     // time): what counts per level is the number of barriers and what the returning atomic that reserves queue space
     // has to overlap with.  Three barriers per level: B (histogram complete) -- reserve, prefix sums, the records'
@@ -517,7 +522,8 @@ static int fill_levels(const int* res, const int* sizes, int levels, int* res_ou
 }
 
 int nerf::launch_hashgrid_gather(const float* x, int64_t P, const float* const* tables, const int* res, const int* sizes,
-                                 int levels, float* out, bool level_major, int64_t level_stride, hipStream_t stream) {
+                                 int levels, float* out, bool level_major, int64_t level_stride, hipStream_t stream,
+                                 const int* count) {
     HashLevels lv;
     if (int rc = fill_levels(res, sizes, levels, lv.res, lv.size)) return rc;
     for (int l = 0; l < levels; ++l) {
@@ -528,10 +534,10 @@ int nerf::launch_hashgrid_gather(const float* x, int64_t P, const float* const* 
     if (grid >= (1ll << 31)) return fail(NERF_EINVAL, "hashgrid: %lld points are too many for one launch", (long long)P);
     if (level_major)
         hipLaunchKernelGGL(hashgrid_fwd_pinned_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, x, P, lv, levels,
-                           (int)nblk, out, level_stride);
+                           (int)nblk, out, level_stride, count);
     else
         hipLaunchKernelGGL(hashgrid_fwd_pinned_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, x, P, lv, levels,
-                           (int)nblk, out, level_stride);
+                           (int)nblk, out, level_stride, count);
     return check_launch("hashgrid_gather");
 }
 
@@ -618,7 +624,7 @@ size_t nerf::hashgrid_scatter_workspace_bytes(int64_t P, const int* sizes, int l
 
 int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, int64_t level_stride, const int* res,
                                   const int* sizes, int levels, float* const* d_tables, void* workspace,
-                                  size_t workspace_bytes, hipStream_t stream) {
+                                  size_t workspace_bytes, hipStream_t stream, const int* count) {
     static std::atomic<bool> lds_enabled[64], red_enabled[64];
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hashgrid_bwd_lds_kernel), lds_enabled,
                                  (int)(HG_LDS_MAX_ROWS * 2 * sizeof(double)))) return rc;
@@ -636,7 +642,7 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
         if (n_lds == 0) return NERF_OK;
         const int blocks = (int)(P / 2048 < 256 ? P / 2048 : 256);
         hipLaunchKernelGGL(hashgrid_bwd_lds_kernel, dim3(blocks, n_lds), dim3(HG_LDS_THREADS), (size_t)lds_rows * 2 * sizeof(double),
-                           stream, x, P, d_enc, ll, levels, level_stride);
+                           stream, x, P, d_enc, ll, levels, level_stride, count);
         n_lds = 0;
         lds_rows = 0;
         return check_launch("hashgrid_scatter(lds)");
@@ -693,7 +699,7 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
         launch_zero_words(counters, (int)(BIN_COUNTER_BYTES / 4), stream);
         if (int rc = check_launch("hashgrid_scatter(clear)")) return rc;
         hipLaunchKernelGGL(hashgrid_bin_kernel, dim3((unsigned)ceil_div(P, BIN_PTS)), dim3(BIN_PTS), 0, stream, x, P, d_enc,
-                           levels, level_stride, bl, counters, queues);
+                           levels, level_stride, bl, counters, queues, count);
         if (int rc = check_launch("hashgrid_scatter(bin)")) return rc;
         hipLaunchKernelGGL(hashgrid_reduce_kernel, dim3(bl.wg_first[bl.n]), dim3(RED_THREADS),
                            (size_t)(BIN_SEG_ROWS + 2) * 2 * sizeof(double), stream, bl, counters, queues);
@@ -701,7 +707,7 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
     }
     if (big == 0) return NERF_OK;
     hipLaunchKernelGGL(hashgrid_bwd_kernel, dim3((unsigned)ceil_div(4 * P, 256), big), dim3(256), 0, stream, x, P, d_enc, lv,
-                       levels, level_stride);
+                       levels, level_stride, count);
     return check_launch("hashgrid_scatter");
 }
 

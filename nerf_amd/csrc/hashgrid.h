@@ -139,8 +139,9 @@ __device__ __forceinline__ float corner_weight(const Cell& c, int corner) {
 
 // The encoding of P points: out[p][2l + f] (row-major) or out[(l * level_stride + p) * 2 + f] (level-major); every
 // level is gathered by the workgroups of one XCD (defined with the encoder kernels).
+// count (may be null): the number of points in use, in device memory; P is then the upper bound the grids are sized for.
 int launch_hashgrid_gather(const float* x, int64_t P, const float* const* tables, const int* res, const int* sizes, int levels,
-                           float* out, bool level_major, int64_t level_stride, hipStream_t stream);
+                           float* out, bool level_major, int64_t level_stride, hipStream_t stream, const int* count = nullptr);
 
 // d_tables[l][row][f] += corner weight * d_enc[p][2l + f] over all points and corners
 // (the backward of the hash-grid gather); defined with the encoder kernels.  d_enc is row-major [P][2 * levels]
@@ -150,6 +151,6 @@ int launch_hashgrid_gather(const float* x, int64_t P, const float* const* tables
 size_t hashgrid_scatter_workspace_bytes(int64_t P, const int* sizes, int levels);
 int launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, int64_t level_stride, const int* res,
                             const int* sizes, int levels, float* const* d_tables, void* workspace, size_t workspace_bytes,
-                            hipStream_t stream);
+                            hipStream_t stream, const int* count = nullptr);
 
 }  // namespace nerf

@@ -775,6 +775,7 @@ struct SkinnyPart {
     float* dW;        // [C][K]
     float* dbias;     // [C]
     int ldY, ldX, c0, C, K;
+    const int* count = nullptr;   // rows in use, in device memory (null: all P32 of them)
 };
 
 // Largest-|entry| bookkeeping of the split-f16 weight gradients: every wavefront of the kernel that writes a

@@ -97,7 +97,8 @@ template <bool SAVE>
 __global__ __launch_bounds__(256, 3) void ngp_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ dirs,
                                                       int dirs_div, long long P,
                                                       const float* __restrict__ pk_arg, float* __restrict__ rgb,
-                                                      float* __restrict__ sigma, float* __restrict__ ws) {
+                                                      float* __restrict__ sigma, float* __restrict__ ws,
+                                                      const int* __restrict__ count) {
     // a wave's 32 x 64 (or 32 x 32) block of a saved matrix is contiguous in memory: its register tiles go through a
     // per-wave LDS transposition buffer and leave as whole rows, 16 bytes per lane (stored straight from the register
     // layout an instruction writes 64 pieces of 16 bytes, 256 bytes apart)
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(256, 3) void ngp_fwd_kernel(const float* __restrict
         *reinterpret_cast<float4*>(s_w + W_FWD + k) = *reinterpret_cast<const float4*>(pk_arg + np::S_BD1 + k);
     __syncthreads();
     const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long P32 = (P + 31) / 32 * 32, tiles = P32 / 32;
+    // P sizes the arrays (their strides are P32); with a count in device memory only the first `used` points are walked
+    const long long P32 = (P + 31) / 32 * 32, used = points_in_use(P, count), tiles = (used + 31) / 32;
 #pragma unroll 1
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < tiles; tile += (long long)gridDim.x * 4) {
         // the lane index is opaque per tile: otherwise every lane's weight offsets (and the weights) are formed in front of
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(256, 3) void ngp_fwd_kernel(const float* __restrict
         asm volatile("" : "+v"(lane));
         const int h = lane >> 5;
         NgpIdx ix;
-        ix.lane = lane; ix.tile = tile; ix.h = h; ix.gp = tile * 32 + (lane & 31); ix.valid = ix.gp < P;
-        ix.lp = ix.valid ? ix.gp : P - 1; ix.P32 = P32;
+        ix.lane = lane; ix.tile = tile; ix.h = h; ix.gp = tile * 32 + (lane & 31); ix.valid = ix.gp < used;
+        ix.lp = ix.valid ? ix.gp : used - 1; ix.P32 = P32;
         auto pk_at = [&](int packed_off) { return packed_off >= np::S_BD1 ? s_w + W_FWD + (packed_off - np::S_BD1) : s_w + (packed_off - np::F_D1); };
         const TileBuf tb = tile_buf(s_tile[wave], lane);
         // ---- hash encoding: levels 8h .. 8h+7 of this lane's point, gathered level by level by the launch before
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void ngp_bwd_fused_kernel(const float* __re
                                                                long long P, const float* __restrict__ pk_arg,
                                                                const float* __restrict__ rgb, const float* __restrict__ sigma,
                                                                const float* __restrict__ ws, float* __restrict__ ws2, NgpGrads g,
-                                                               float* __restrict__ partials) {
+                                                               float* __restrict__ partials, const int* __restrict__ count) {
     __shared__ __attribute__((aligned(16))) float s_at[4][AT_FLOATS];
     // The backward weights (three transposed layers and the colour head's 3 x 64) stay in LDS for all the tiles the
     // workgroup walks: read from L2 per tile their latency showed between the chain's MFMAs at two waves per SIMD.
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void ngp_bwd_fused_kernel(const float* __re
     if (threadIdx.x < 192) s_w[W_CHAIN + threadIdx.x] = pk_arg[np::S_WC2 + threadIdx.x];
     __syncthreads();
     const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long P32 = (P + 31) / 32 * 32, tiles = P32 / 32;
+    const long long P32 = (P + 31) / 32 * 32, used = points_in_use(P, count), tiles = (used + 31) / 32;
     f32x16 acc_c1[2][2], acc_d2[1][2], acc_d1[2][1];
     float b_c1[2] = {0.f, 0.f}, b_d2[1] = {0.f}, b_d1[2] = {0.f, 0.f};
 #pragma unroll
@@ -322,8 +324,8 @@ __global__ __launch_bounds__(256, 2) void ngp_bwd_fused_kernel(const float* __re
         float* s_a = s_at[wave];
         const float* w_c1t = s_w, *w_d2t = s_w + (np::B_D2 - np::B_C1), *w_d1t = s_w + (np::B_D1 - np::B_C1), *w_c2 = s_w + W_CHAIN;
         const long long gp = tile * 32 + p;
-        const bool valid = gp < P;
-        const long long lp = valid ? gp : P - 1;
+        const bool valid = gp < used;
+        const long long lp = valid ? gp : used - 1;
         const unsigned* mask = reinterpret_cast<const unsigned*>(ws + P32 * nw::MASK) + tile * 128 + lane;
         const unsigned m_hd = mask[0], m_hc = mask[64];
         float dpre[3], dps = 0.0f;
@@ -564,30 +566,43 @@ static int check_levels(const int* res, const int* sizes, const char* who) {
     return NERF_OK;
 }
 
-extern "C" int nerf_mlp_ngp_fwd(const float* x, const float* dirs, int dirs_div, int64_t P, const float* const* tables,
-                                const int* res, const int* sizes, const float* packed, float* rgb, float* sigma,
-                                float* ws, float* enc, void* stream) {
+static int ngp_fwd(const float* x, const float* dirs, int dirs_div, int64_t P, const float* const* tables, const int* res,
+                   const int* sizes, const float* packed, float* rgb, float* sigma, float* ws, float* enc,
+                   const int32_t* count, void* stream) {
     if (P == 0) return NERF_OK;
     NERF_REQUIRE(x && tables && res && sizes && packed && rgb && sigma && enc, "nerf_mlp_ngp_fwd: null pointer");
     NERF_REQUIRE(P >= 0 && dirs_div >= 1, "nerf_mlp_ngp_fwd: P=%lld dirs_div=%d", (long long)P, dirs_div);
     if (int rc = check_levels(res, sizes, "nerf_mlp_ngp_fwd")) return rc;
     const long long P32 = (P + 31) / 32 * 32;
-    if (int rc = launch_hashgrid_gather(x, P, tables, res, sizes, 16, enc, true, P32, (hipStream_t)stream)) return rc;
+    if (int rc = launch_hashgrid_gather(x, P, tables, res, sizes, 16, enc, true, P32, (hipStream_t)stream, count)) return rc;
     const long long wgs = ceil_div(P, 128);
     const dim3 grid((unsigned)(wgs < 768 ? wgs : 768)), block(256);   // three workgroups per CU, each walking its share of the tiles
     if (ws)
         hipLaunchKernelGGL(ngp_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, enc, dirs, dirs_div, (long long)P,
-                           packed, rgb, sigma, ws);
+                           packed, rgb, sigma, ws, count);
     else
         hipLaunchKernelGGL(ngp_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, enc, dirs, dirs_div, (long long)P,
-                           packed, rgb, sigma, ws);
+                           packed, rgb, sigma, ws, count);
     return check_launch("nerf_mlp_ngp_fwd");
 }
 
-extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, int64_t P, const int* res,
-                                const int* sizes, const float* packed, const float* rgb, const float* sigma, float* ws,
-                                float* ws2, float* const* d_tables, float* const* grads, void* scatter_ws,
-                                size_t scatter_ws_bytes, int phases, void* stream) {
+extern "C" int nerf_mlp_ngp_fwd(const float* x, const float* dirs, int dirs_div, int64_t P, const float* const* tables,
+                                const int* res, const int* sizes, const float* packed, float* rgb, float* sigma,
+                                float* ws, float* enc, void* stream) {
+    return ngp_fwd(x, dirs, dirs_div, P, tables, res, sizes, packed, rgb, sigma, ws, enc, nullptr, stream);
+}
+
+extern "C" int nerf_mlp_ngp_fwd_counted(const float* x, const float* dirs, int dirs_div, int64_t P_max, const int32_t* count,
+                                        const float* const* tables, const int* res, const int* sizes, const float* packed,
+                                        float* rgb, float* sigma, float* ws, float* enc, void* stream) {
+    NERF_REQUIRE(count, "nerf_mlp_ngp_fwd_counted: null count");
+    return ngp_fwd(x, dirs, dirs_div, P_max, tables, res, sizes, packed, rgb, sigma, ws, enc, count, stream);
+}
+
+static int ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, int64_t P, const int* res, const int* sizes,
+                   const float* packed, const float* rgb, const float* sigma, float* ws, float* ws2, float* const* d_tables,
+                   float* const* grads, void* scatter_ws, size_t scatter_ws_bytes, int phases, const int32_t* count,
+                   void* stream) {
     if (P == 0) return NERF_OK;
     NERF_REQUIRE(x && d_rgb && d_sigma && res && sizes && packed && rgb && sigma && ws && ws2 && d_tables && grads,
                  "nerf_mlp_ngp_bwd: null pointer");
@@ -609,9 +624,9 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
         // the backward-data chain with the weight-gradient sums of the three layers it walks, then the table gradients:
         // d_tables is complete when these launches are
         hipLaunchKernelGGL(ngp_bwd_fused_kernel, dim3((unsigned)wgs), dim3(256), 0, st, d_rgb, d_sigma,
-                           (long long)P, packed, rgb, sigma, ws, ws2, g, partials);
+                           (long long)P, packed, rgb, sigma, ws, ws2, g, partials, count);
         if (int rc = check_launch("nerf_mlp_ngp_bwd(chain)")) return rc;
-        if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, P32, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st)) return rc;
+        if (int rc = launch_hashgrid_scatter(x, P, ws2 + P32 * nw::DENC, P32, res, sizes, 16, d_tables, scatter_ws, scatter_ws_bytes, st, count)) return rc;
     }
     if (!(phases & 2)) return NERF_OK;
     if (partials) {   // grads += the workgroups' sums, in a fixed order
@@ -620,5 +635,24 @@ extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float*
         if (int rc = check_launch("nerf_mlp_ngp_bwd(reduce)")) return rc;
     }
     SkinnyPart c2{ws2 + P32 * nw::DOUT4, ws + P32 * nw::HC, grads[6], grads[7], 4, 64, 1, 3, 64};   // fc_color.2: d(sigma, rgb)_pre x hc
+    c2.count = count;
     return launch_skinny(c2, P32, st);
+}
+
+extern "C" int nerf_mlp_ngp_bwd(const float* x, const float* d_rgb, const float* d_sigma, int64_t P, const int* res,
+                                const int* sizes, const float* packed, const float* rgb, const float* sigma, float* ws,
+                                float* ws2, float* const* d_tables, float* const* grads, void* scatter_ws,
+                                size_t scatter_ws_bytes, int phases, void* stream) {
+    return ngp_bwd(x, d_rgb, d_sigma, P, res, sizes, packed, rgb, sigma, ws, ws2, d_tables, grads, scatter_ws, scatter_ws_bytes,
+                   phases, nullptr, stream);
+}
+
+extern "C" int nerf_mlp_ngp_bwd_counted(const float* x, const float* d_rgb, const float* d_sigma, int64_t P_max,
+                                        const int32_t* count, const int* res, const int* sizes, const float* packed,
+                                        const float* rgb, const float* sigma, float* ws, float* ws2, float* const* d_tables,
+                                        float* const* grads, void* scatter_ws, size_t scatter_ws_bytes, int phases,
+                                        void* stream) {
+    NERF_REQUIRE(count, "nerf_mlp_ngp_bwd_counted: null count");
+    return ngp_bwd(x, d_rgb, d_sigma, P_max, res, sizes, packed, rgb, sigma, ws, ws2, d_tables, grads, scatter_ws,
+                   scatter_ws_bytes, phases, count, stream);
 }

@@ -449,9 +449,11 @@ int launch_wgrad(WgradParts& parts, long long P32, hipStream_t stream) {
 // with 2048 workgroups of 256 threads they, not the reads, set the time (65 us for a 67 MB read).
 constexpr int SKINNY_THREADS = 1024;
 template <int K>
-__global__ __launch_bounds__(SKINNY_THREADS) void skinny_wgrad_kernel(SkinnyPart pt, long long P32) {
+__global__ __launch_bounds__(SKINNY_THREADS) void skinny_wgrad_kernel(SkinnyPart pt, long long P32_max) {
     constexpr int L = K / 4, R = SKINNY_THREADS / L;     // threads per row, rows per pass
     __shared__ float red[R][4][K];
+    // rows up to the end of the last tile in use: the rows behind the last point hold zeros in dY
+    const long long P32 = (points_in_use(P32_max, pt.count) + 31) / 32 * 32;
     const int c4 = threadIdx.x % L, rs = threadIdx.x / L;
     const long long per = (P32 + gridDim.x - 1) / gridDim.x;
     const long long p0 = per * blockIdx.x, p1 = min(P32, p0 + per);

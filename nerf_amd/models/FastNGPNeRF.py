@@ -56,10 +56,11 @@ class FastNGPNeRF(nn.Module):
                 self.fc_density[2].bias, self.fc_color[0].weight, self.fc_color[0].bias, self.fc_color[2].weight,
                 self.fc_color[2].bias, self.skip_proj.weight]
 
-    def forward(self, x, view_dirs=None, dirs_div=1):
+    def forward(self, x, view_dirs=None, dirs_div=1, count=None):
         """x [N,3] (unit-cube / unit-sphere coordinates, may be negative), view_dirs [N,3] or None
-        -> rgb [N,3], sigma [N].  ``dirs_div`` > 1 lets one direction row serve that many consecutive points."""
-        return ops.ngp_mlp(x, view_dirs, self._tables(), self._params(), self.hash_encoder.resolutions, dirs_div)
+        -> rgb [N,3], sigma [N].  ``dirs_div`` > 1 lets one direction row serve that many consecutive points.
+        ``count`` (one int32 on the GPU): only the first ``count`` rows are in use (``ops.ngp_mlp``)."""
+        return ops.ngp_mlp(x, view_dirs, self._tables(), self._params(), self.hash_encoder.resolutions, dirs_div, count)
 
     @torch.no_grad()
     def query_density(self, x):

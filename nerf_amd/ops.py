@@ -274,12 +274,15 @@ def occupancy_mask(sigma, pts, grid, grid_res: int):
     return _OccupancyMask.apply(sigma, pts, grid, int(grid_res))
 
 
-def occupancy_compact(pts, grid, grid_res: int, dirs=None, dirs_div: int = 1):
+def occupancy_compact(pts, grid, grid_res: int, dirs=None, dirs_div: int = 1, read_count: bool = True):
     """The samples of ``pts`` [P,3] that lie in occupied cells of the uint8 ``grid``, in their own order:
     returns ``(kept int32 [K], slot int32 [P], pts_kept [K,3], dirs_kept [K,3] | None)`` -- ``kept`` the indices,
     ``slot[p]`` the position of sample p among them or -1, ``dirs_kept`` the rows of ``dirs`` (one per ``dirs_div``
     consecutive samples) the kept samples belong to.  K is read back from the GPU (one small device-to-host copy:
-    a step that skips samples has data-dependent sizes and cannot be captured into a HIP graph)."""
+    a step whose tensors have data-dependent sizes cannot be captured into a HIP graph).
+    ``read_count=False`` reads nothing back: ``(count int32 [1] on the GPU, slot, pts_kept [P,3], dirs_kept [P,3] | None)``
+    with the arrays at their full size and only their first ``count`` rows meaningful -- for callees that take the
+    count from device memory (``ngp_mlp(..., count=)``)."""
     L.need_gpu(pts, grid, dirs)
     pc = L.f32c(pts.detach()).reshape(-1, 3)
     if grid.dtype != torch.uint8:
@@ -299,39 +302,48 @@ def occupancy_compact(pts, grid, grid_res: int, dirs=None, dirs_div: int = 1):
     L.check(lib.nerf_occupancy_compact(L.ptr(pc), P, L.ptr(gc), gc.numel(), int(grid_res), L.ptr(dc), int(dirs_div),
                                        L.ptr(work), L.ptr(kept), L.ptr(slot), L.ptr(pts_k), L.ptr(dirs_k), L.ptr(count),
                                        L.stream_of(pc)), "nerf_occupancy_compact")
+    if not read_count:
+        return count, slot, pts_k, dirs_k
     K = int(count.item())
     return kept[:K], slot, pts_k[:K], (dirs_k[:K] if dirs_k is not None else None)
 
 
 class _ExpandKept(torch.autograd.Function):
     """(rgb_kept [K,3], sigma_kept [K]) -> (rgb [P,3], sigma [P]): the kept samples' values at their places, zeros at the
-    dropped ones; backward gathers the kept samples' gradients."""
+    dropped ones; backward gathers the kept samples' gradients.  ``kept`` None: the count stayed on the device, the
+    compact arrays have all P rows and ``slot`` alone says which of them are in use."""
 
     @staticmethod
     def forward(ctx, rgb_k, sigma_k, kept, slot):
         L.need_gpu(rgb_k, sigma_k, kept, slot)
         rc, sc = L.f32c(rgb_k.detach()).reshape(-1, 3), L.f32c(sigma_k.detach()).reshape(-1)
-        P, K = slot.shape[0], kept.shape[0]
+        P = slot.shape[0]
+        K = kept.shape[0] if kept is not None else P
         L.require(rc.shape[0] == K and sc.shape[0] == K, "one model output per kept sample")
         rgb = torch.empty(P, 3, device=slot.device)
         sigma = torch.empty(P, device=slot.device)
         L.check(L.lib().nerf_expand_kept(L.ptr(rc), L.ptr(sc), L.ptr(slot), P, L.ptr(rgb), L.ptr(sigma), L.stream_of(slot)),
                 "nerf_expand_kept")
-        ctx.save_for_backward(kept)
+        ctx.by_slot = kept is None
+        ctx.save_for_backward(slot if kept is None else kept)
         ctx.shapes = (rgb_k.shape, sigma_k.shape)
         ctx.set_materialize_grads(False)
         return rgb, sigma
 
     @staticmethod
     def backward(ctx, d_rgb, d_sigma):
-        (kept,) = ctx.saved_tensors
-        K = kept.shape[0]
+        (index,) = ctx.saved_tensors
+        K = index.shape[0]
         d_rgb = L.f32c(d_rgb) if d_rgb is not None else None
         d_sigma = L.f32c(d_sigma) if d_sigma is not None else None
-        g_rgb = torch.empty(K, 3, device=kept.device)
-        g_sigma = torch.empty(K, device=kept.device)
-        L.check(L.lib().nerf_gather_kept(L.ptr(d_rgb), L.ptr(d_sigma), L.ptr(kept), K, L.ptr(g_rgb), L.ptr(g_sigma),
-                                         L.stream_of(kept)), "nerf_gather_kept")
+        g_rgb = torch.empty(K, 3, device=index.device)
+        g_sigma = torch.empty(K, device=index.device)
+        if ctx.by_slot:   # rows behind the count stay as they are: their consumer does not read them
+            L.check(L.lib().nerf_gather_kept_by_slot(L.ptr(d_rgb), L.ptr(d_sigma), L.ptr(index), K, L.ptr(g_rgb), L.ptr(g_sigma),
+                                                     L.stream_of(index)), "nerf_gather_kept_by_slot")
+        else:
+            L.check(L.lib().nerf_gather_kept(L.ptr(d_rgb), L.ptr(d_sigma), L.ptr(index), K, L.ptr(g_rgb), L.ptr(g_sigma),
+                                             L.stream_of(index)), "nerf_gather_kept")
         return g_rgb.view(ctx.shapes[0]), g_sigma.view(ctx.shapes[1]), None, None
 
 
@@ -552,10 +564,12 @@ class _NgpMLP(torch.autograd.Function):
     """Fused hash-grid NeRF: (x [P,3], dirs | None, 16 tables, 9 MLP parameters) ->
     (rgb [P,3], sigma [P]).  MLP parameter order: fc_density.0.{weight,bias},
     fc_density.2.{weight,bias}, fc_color.0.{weight,bias}, fc_color.2.{weight,bias},
-    skip_proj.weight.  Gradients go to the tables and the parameters."""
+    skip_proj.weight.  Gradients go to the tables and the parameters.
+    ``count`` (one int32 on the GPU, or None): only the first ``count`` points are in use -- x, dirs and the outputs
+    keep their full size P, nothing is read back, rows behind the count are neither read nor written."""
 
     @staticmethod
-    def forward(ctx, x, dirs, dirs_div, res, grad_mode, *tensors):
+    def forward(ctx, x, dirs, dirs_div, res, grad_mode, count, *tensors):
         tables, params = tensors[:16], tensors[16:]
         L.require(len(tables) == 16 and len(params) == 9, "the hash-grid model has 16 tables and 9 other parameter tensors")
         L.need_gpu(x, dirs, *tensors)
@@ -573,12 +587,20 @@ class _NgpMLP(torch.autograd.Function):
         L.check(lib.nerf_mlp_ngp_pack(L.ptr_array(ps), L.ptr(packed), st), "nerf_mlp_ngp_pack")
         rgb = torch.empty(P, 3, device=dev)
         sigma = torch.empty(P, device=dev)
-        train = grad_mode and any(ctx.needs_input_grad[5:])   # see _VanillaMLP.forward
+        train = grad_mode and any(ctx.needs_input_grad[6:])   # see _VanillaMLP.forward
         ws = torch.empty(_ceil32(P) * lib.nerf_mlp_ngp_ws_floats_per_point(), device=dev) if train and P else None
         enc = torch.empty(_ceil32(P) * 32, device=dev)   # the encoding, level-major, between the two launches
-        L.check(lib.nerf_mlp_ngp_fwd(L.ptr(xc), L.ptr(dc), int(dirs_div), P, L.ptr_array(tabs), L.int_array(res),
-                                     L.int_array(sizes), L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(enc), st),
-                "nerf_mlp_ngp_fwd")
+        if count is None:
+            L.check(lib.nerf_mlp_ngp_fwd(L.ptr(xc), L.ptr(dc), int(dirs_div), P, L.ptr_array(tabs), L.int_array(res),
+                                         L.int_array(sizes), L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(enc), st),
+                    "nerf_mlp_ngp_fwd")
+        else:
+            L.need_gpu(count)
+            L.require(count.dtype == torch.int32 and count.numel() == 1, "count must be one int32")
+            L.check(lib.nerf_mlp_ngp_fwd_counted(L.ptr(xc), L.ptr(dc), int(dirs_div), P, L.ptr(count), L.ptr_array(tabs),
+                                                 L.int_array(res), L.int_array(sizes), L.ptr(packed), L.ptr(rgb), L.ptr(sigma),
+                                                 L.ptr(ws), L.ptr(enc), st), "nerf_mlp_ngp_fwd_counted")
+        ctx.count = count
         if train:
             ctx.save_for_backward(xc, packed, rgb, sigma, ws)
             ctx.meta = (P, list(res), sizes, [t.shape for t in tensors])
@@ -593,8 +615,9 @@ class _NgpMLP(torch.autograd.Function):
         P, res, sizes, shapes = ctx.meta
         lib = L.lib()
         dev = rgb.device
+        count = ctx.count
         if P == 0:
-            return (None, None, None, None, None, *zero_grads_like(shapes, dev))
+            return (None, None, None, None, None, None, *zero_grads_like(shapes, dev))
         grads, sink = _grad_targets(ctx.params, shapes, dev, ctx.expected)
         d_rgb = L.f32c(d_rgb) if d_rgb is not None else torch.zeros(P, 3, device=dev)
         d_sigma = L.f32c(d_sigma) if d_sigma is not None else torch.zeros(P, device=dev)
@@ -602,10 +625,16 @@ class _NgpMLP(torch.autograd.Function):
         work, nbytes = scatter_workspace(P, sizes, dev)
 
         def run(phases):
-            L.check(lib.nerf_mlp_ngp_bwd(L.ptr(xc), L.ptr(d_rgb), L.ptr(d_sigma), P, L.int_array(res), L.int_array(sizes),
-                                         L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(ws2),
-                                         L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.ptr(work), nbytes, phases,
-                                         L.stream_of(rgb)), "nerf_mlp_ngp_bwd")
+            if count is None:
+                L.check(lib.nerf_mlp_ngp_bwd(L.ptr(xc), L.ptr(d_rgb), L.ptr(d_sigma), P, L.int_array(res), L.int_array(sizes),
+                                             L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws), L.ptr(ws2),
+                                             L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.ptr(work), nbytes, phases,
+                                             L.stream_of(rgb)), "nerf_mlp_ngp_bwd")
+            else:
+                L.check(lib.nerf_mlp_ngp_bwd_counted(L.ptr(xc), L.ptr(d_rgb), L.ptr(d_sigma), P, L.ptr(count), L.int_array(res),
+                                                     L.int_array(sizes), L.ptr(packed), L.ptr(rgb), L.ptr(sigma), L.ptr(ws),
+                                                     L.ptr(ws2), L.ptr_array(grads[:16]), L.ptr_array(grads[16:]), L.ptr(work),
+                                                     nbytes, phases, L.stream_of(rgb)), "nerf_mlp_ngp_bwd_counted")
 
         if sink is not None:
             # the table gradients (41.7 MB, the one sizeable exchange of data-parallel training) are complete after the
@@ -614,13 +643,13 @@ class _NgpMLP(torch.autograd.Function):
             sink.done(ctx.params[:16])
             run(2)
             sink.done(ctx.params[16:])
-            return (None,) * (5 + len(grads))
+            return (None,) * (6 + len(grads))
         run(3)
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
-def ngp_mlp(x, dirs, tables, params, res, dirs_div: int = 1):
-    return _NgpMLP.apply(x, dirs, int(dirs_div), list(res), torch.is_grad_enabled(), *tables, *params)
+def ngp_mlp(x, dirs, tables, params, res, dirs_div: int = 1, count=None):
+    return _NgpMLP.apply(x, dirs, int(dirs_div), list(res), torch.is_grad_enabled(), count, *tables, *params)
 
 
 # ------------------------------------------------------------ optimiser ----

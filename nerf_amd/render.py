@@ -32,10 +32,19 @@ def _eval_model(model, pts, view_dirs, n_per_ray):
     return rgb.view(R, N, 3), sigma.reshape(R, N)
 
 
-def _eval_model_occupied(model, pts, view_dirs, density_grid, grid_res):
+def _eval_model_occupied(model, pts, view_dirs, density_grid, grid_res, on_device: bool = False):
     """``_eval_model`` on the samples in occupied cells only; the others get sigma = 0 (what the mask gives them) and
-    rgb = 0 (their weight is 0 either way)."""
+    rgb = 0 (their weight is 0 either way).  ``on_device``: the number of kept samples is not read back -- the model takes
+    it from device memory and every tensor keeps its full size (hash-grid model only)."""
     R, N = pts.shape[0], pts.shape[1]
+    if on_device:
+        if not hasattr(model, "_tables"):
+            raise NotImplementedError("skip_empty='device' is built for the hash-grid model; the 8x256 kernels take their "
+                                      "point count from the host")
+        count, slot, pts_k, dirs_k = ops.occupancy_compact(pts, density_grid, grid_res, view_dirs, N, read_count=False)
+        rgb_k, sigma_k = model(pts_k, dirs_k, count=count)
+        rgb, sigma = ops.expand_kept(rgb_k, sigma_k, None, slot)
+        return rgb.view(R, N, 3), sigma.view(R, N)
     kept, slot, pts_k, dirs_k = ops.occupancy_compact(pts, density_grid, grid_res, view_dirs, N)
     if hasattr(model, "_params") and hasattr(model, "_skip_h_first"):
         rgb_k, sigma_k = ops.vanilla_mlp(pts_k, dirs_k, model._params(), model._skip_h_first)
@@ -55,7 +64,7 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
                 t_rand: Optional[torch.Tensor] = None, white_bkgd: bool = False, fine_model=None,
                 n_importance: int = 0, u_fine: Optional[torch.Tensor] = None, ndc=None,
                 density_grid: Optional[torch.Tensor] = None, grid_res: Optional[int] = None,
-                z_lin: Optional[torch.Tensor] = None, samples=None, skip_empty: bool = False):
+                z_lin: Optional[torch.Tensor] = None, samples=None, skip_empty=False):
     """Render a batch of rays [R,3].
 
     Returns a dict with ``rgb`` [R,3], ``weights`` [R,N], ``z_vals`` [R,N],
@@ -73,7 +82,9 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
     before compositing, as the hash-grid training render does (src/train_nerf_ngp.py:113-117).  With
     ``skip_empty`` those samples are dropped BEFORE the model instead (it runs on the occupied ones only): the same
     colours, weights and depths -- a sample with zero density has zero weight and no gradient -- for a fraction of the
-    work; the sizes become data-dependent, so such a step cannot be captured into a HIP graph.
+    work; the sizes become data-dependent, so such a step cannot be captured into a HIP graph.  ``skip_empty="device"``
+    (hash-grid model) keeps the sizes fixed instead: the number of kept samples stays in device memory, the kernels are
+    launched for all of them and leave early -- nothing is read back and the step can be captured.
     ``samples = (z_vals [R,N], pts [R,N,3])`` supplies coarse samples already drawn (by the fused
     ``ops.raygen_sample``), in which case ``t_rand`` / ``perturb`` / ``z_lin`` are not used.
     """
@@ -92,9 +103,10 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
         if perturb and t_rand is None:
             t_rand = torch.rand(R, n_samples, device=dev)
         z, pts = ops.stratified_sample(rays_o, rays_d, z_lin, t_rand if perturb else None)
-    skip = skip_empty and density_grid is not None
+    skip = bool(skip_empty) and density_grid is not None
+    on_device = skip_empty == "device"
     if skip:
-        rgb, sigma = _eval_model_occupied(model, pts, view_dirs, density_grid, grid_res)
+        rgb, sigma = _eval_model_occupied(model, pts, view_dirs, density_grid, grid_res, on_device)
     else:
         rgb, sigma = _eval_model(model, pts, view_dirs, n_samples)
         if density_grid is not None:
@@ -106,7 +118,7 @@ def render_rays(model, rays_o, rays_d, near: float, far: float, n_samples: int, 
             u_fine = torch.rand(R, n_importance, device=dev)
         _, _, z_all, pts_f = ops.pdf_sample(rays_o, rays_d, z, w, u_fine, want_fine=False)
         if skip:
-            rgb_f, sigma_f = _eval_model_occupied(fine_model, pts_f, view_dirs, density_grid, grid_res)
+            rgb_f, sigma_f = _eval_model_occupied(fine_model, pts_f, view_dirs, density_grid, grid_res, on_device)
         else:
             rgb_f, sigma_f = _eval_model(fine_model, pts_f, view_dirs, n_samples + n_importance)
             if density_grid is not None:

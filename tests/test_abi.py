@@ -24,7 +24,7 @@ def test_header_and_binding_agree():
 def test_library_exports_all_symbols():
     from nerf_amd import _lib
     handle = _lib.lib()  # raises if the library is missing or a symbol is absent
-    assert handle.nerf_abi_version() == 3
+    assert handle.nerf_abi_version() == 4
     for name in _declared_symbols():
         assert hasattr(handle, name), name
 

@@ -157,3 +157,61 @@ def test_render_with_nothing_occupied(dev, kind):
     img = render_image(m, o.view(12, 12, 3), d.view(12, 12, 3), 0.05, 1.8, n_samples=24, grid_res=32, density_grid=grid,
                        skip_empty=True, white_bkgd=(kind == "vanilla"))
     assert float((img - background).abs().max()) == 0.0
+
+
+def test_skipping_with_the_count_left_on_the_device(dev):
+    """``skip_empty="device"``: no read-back, full-size tensors, the kernels take the number of kept samples from device
+    memory.  The render equals the masked one bit for bit, the gradients up to summation order -- eagerly and replayed
+    from a HIP graph with other batches copied in (the count changes from replay to replay)."""
+    from nerf_amd.dist import GradBuckets
+    from nerf_amd.graph import GraphedStep
+    from nerf_amd.optim import FusedAdam
+    from nerf_amd.render import ngp_loss, render_rays, train_step
+    m = _ngp_with_structure(dev)
+    o, d = _rays(40, dev)                      # 1600 rays x 48 samples = 76,800 points: the binned scatter
+    N = 48
+    grid = _ball_grid(32, 0.55).to(dev)
+    gen = torch.Generator().manual_seed(3)
+    u = torch.rand(o.shape[0], N, generator=gen).to(dev)
+    gt = torch.rand(o.shape[0], 3, generator=gen).to(dev)
+    res = {}
+    for mode in (False, True, "device"):
+        for p in m.parameters():
+            p.grad = None
+        out = render_rays(m, o, d, 0.05, 1.8, N, t_rand=u, density_grid=grid, grid_res=32, skip_empty=mode)
+        ngp_loss(out, gt).backward()
+        res[mode] = (out, {k: p.grad.clone() for k, p in m.named_parameters()})
+    for key in ("rgb", "weights", "depth"):
+        assert torch.equal(res["device"][0][key], res[False][0][key]), key
+    for k, g in res[False][1].items():
+        assert float(g.abs().max()) > 0, k
+        assert rel_err(res["device"][1][k], g) < 1e-5, (k, rel_err(res["device"][1][k], g))
+        assert rel_err(res["device"][1][k], res[True][1][k]) < 1e-5, k
+    # an empty and a full grid through the same path
+    for g_all, want in ((torch.zeros_like(grid), 0.0), (torch.ones_like(grid), None)):
+        out = render_rays(m, o, d, 0.05, 1.8, N, t_rand=u, density_grid=g_all, grid_res=32, skip_empty="device")
+        ref = render_rays(m, o, d, 0.05, 1.8, N, t_rand=u, density_grid=g_all, grid_res=32)
+        assert torch.equal(out["rgb"], ref["rgb"]) and (want is None or float(out["rgb"].detach().abs().max()) == want)
+
+    # captured: lr 0 so that every replay sees the same parameters; the rays (and with them the count) change per replay
+    buckets = GradBuckets([list(m.hash_encoder.parameters()), [p for n, p in m.named_parameters() if not n.startswith("hash_encoder")]])
+    opt = FusedAdam(buckets.parameters(), lr=0.0, eps=1e-15, capturable=True)
+    s_o, s_d = o.clone(), d.clone()
+    z_lin = torch.linspace(0.05, 1.8, N).to(dev)
+
+    def step(mode):
+        loss = train_step(m, s_o, s_d, gt, 0.05, 1.8, N, loss_fn=ngp_loss, buckets=buckets, t_rand=u, z_lin=z_lin,
+                          density_grid=grid, grid_res=32, skip_empty=mode)
+        opt.step()
+        return loss
+
+    g = GraphedStep(lambda: step("device"), warmup=2, optimizers=[opt])
+    for shift in (0.0, 0.3, -0.2):
+        s_o.copy_(o + torch.tensor([shift, 0.0, 0.0], device=dev))
+        torch.cuda.synchronize()
+        loss_g = float(g())
+        got = [f.clone() for f in buckets.flats]
+        loss_e = float(step(False))
+        for a, b in zip(got, buckets.flats):
+            assert rel_err(a, b) < 1e-5, (shift, rel_err(a, b))
+        assert abs(loss_g - loss_e) <= 1e-6 * max(1.0, abs(loss_e)), (shift, loss_g, loss_e)
