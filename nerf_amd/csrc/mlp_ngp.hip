@@ -53,16 +53,6 @@ struct NgpIdx {
     int lane, h;
     bool valid;
 };
-__device__ __forceinline__ bool ngp_index(long long P, NgpIdx& ix) {
-    ix.lane = threadIdx.x & 63;
-    ix.tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    ix.h = ix.lane >> 5;
-    ix.gp = ix.tile * 32 + (ix.lane & 31);
-    ix.valid = ix.gp < P;
-    ix.lp = ix.valid ? ix.gp : P - 1;
-    ix.P32 = (P + 31) / 32 * 32;
-    return ix.tile * 32 < P;
-}
 
 // 32 bits: 1 where the post-ReLU activation of a 64-wide layer is > 0 (this lane's 32 neurons).
 __device__ __forceinline__ unsigned relu_bits2(const f32x16 (&a)[2]) {
