@@ -611,6 +611,8 @@ static BinPlan bin_plan(int64_t P, int size) {
     return pl;
 }
 
+int nerf::hashgrid_scatter_counter_words() { return (int)(BIN_COUNTER_BYTES / 4); }
+
 size_t nerf::hashgrid_scatter_workspace_bytes(int64_t P, const int* sizes, int levels) {
     if (P < BIN_MIN_POINTS || 5 * P >= (1ll << 31)) return 0;
     size_t records = 0;
@@ -624,7 +626,7 @@ size_t nerf::hashgrid_scatter_workspace_bytes(int64_t P, const int* sizes, int l
 
 int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, int64_t level_stride, const int* res,
                                   const int* sizes, int levels, float* const* d_tables, void* workspace,
-                                  size_t workspace_bytes, hipStream_t stream, const int* count) {
+                                  size_t workspace_bytes, hipStream_t stream, const int* count, bool counters_cleared) {
     static std::atomic<bool> lds_enabled[64], red_enabled[64];
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(hashgrid_bwd_lds_kernel), lds_enabled,
                                  (int)(HG_LDS_MAX_ROWS * 2 * sizeof(double)))) return rc;
@@ -696,8 +698,10 @@ int nerf::launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc,
                                      (int)((BIN_SEG_ROWS + 2) * 2 * sizeof(double)))) return rc;
         unsigned* counters = reinterpret_cast<unsigned*>(workspace);
         float4* queues = reinterpret_cast<float4*>(reinterpret_cast<char*>(workspace) + BIN_COUNTER_BYTES);
-        launch_zero_words(counters, (int)(BIN_COUNTER_BYTES / 4), stream);
-        if (int rc = check_launch("hashgrid_scatter(clear)")) return rc;
+        if (!counters_cleared) {
+            launch_zero_words(counters, (int)(BIN_COUNTER_BYTES / 4), stream);
+            if (int rc = check_launch("hashgrid_scatter(clear)")) return rc;
+        }
         hipLaunchKernelGGL(hashgrid_bin_kernel, dim3((unsigned)ceil_div(P, BIN_PTS)), dim3(BIN_PTS), 0, stream, x, P, d_enc,
                            levels, level_stride, bl, counters, queues, count);
         if (int rc = check_launch("hashgrid_scatter(bin)")) return rc;

@@ -151,6 +151,9 @@ int launch_hashgrid_gather(const float* x, int64_t P, const float* const* tables
 size_t hashgrid_scatter_workspace_bytes(int64_t P, const int* sizes, int levels);
 int launch_hashgrid_scatter(const float* x, int64_t P, const float* d_enc, int64_t level_stride, const int* res,
                             const int* sizes, int levels, float* const* d_tables, void* workspace, size_t workspace_bytes,
-                            hipStream_t stream, const int* count = nullptr);
+                            hipStream_t stream, const int* count = nullptr, bool counters_cleared = false);
+// The first words of a binned scatter's workspace are its queue counters; a caller that clears them itself (in a kernel
+// it launches anyway, just before) says so with counters_cleared.
+int hashgrid_scatter_counter_words();
 
 }  // namespace nerf
