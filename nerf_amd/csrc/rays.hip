@@ -206,7 +206,29 @@ template <int J>
 __device__ __forceinline__ float xor_lane(float v) {
     if constexpr (J == 1) return dpp_move<0xB1>(v, v);        // quad_perm [1,0,3,2]
     else if constexpr (J == 2) return dpp_move<0x4E>(v, v);   // quad_perm [2,3,0,1]
-    else return __shfl_xor(v, J, 64);
+    else if constexpr (J == 8) return dpp_move<0x128>(v, v);  // row_ror:8 (rows of 16 lanes)
+    else if constexpr (J == 4) {   // banks 0 and 2 of each row read four lanes up, banks 1 and 3 four lanes down
+        const int up = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), DPP_ROW_SHL + 4, 0xf, 0x5, false);
+        return __int_as_float(__builtin_amdgcn_update_dpp(up, __float_as_int(v), DPP_ROW_SHR + 4, 0xf, 0xA, false));
+    } else if constexpr (J == 16) {   // the swap exchanges the odd rows of its first operand with the even rows of its second
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+    } else {                          // 32: the upper half of the first operand with the lower half of the second
+        static_assert(J == 32, "partner distances within a wavefront");
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+    }
+}
+
+// The lanes that keep the smaller value in the exchange at distance j < 64 of the stage forming sorted runs of `size`
+// (register k of the lane: element k*64 + lane; the last stage, size == total, sorts everything upwards).
+constexpr unsigned long long bitonic_min_lanes(int size, int j, int k, int total) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const bool asc = ((k * 64 + l) & size) == 0 || size == total, lower = (l & j) == 0;
+        if (lower == asc) m |= 1ull << l;
+    }
+    return m;
 }
 
 // Ascending bitonic sort of 64*EPL values; element e = k*64 + lane lives in v[k] of the lane.
@@ -216,23 +238,31 @@ __device__ __forceinline__ void wave_bitonic_sort(float (&v)[EPL], int lane) {
         constexpr int SIZE = 1 << decltype(cs)::value;   // length of the sorted runs being formed
         static_for<0, decltype(cs)::value>([&](auto cj) {
             constexpr int J = SIZE >> (1 + decltype(cj)::value);   // partner distance
-#pragma unroll
-            for (int k = 0; k < EPL; ++k) {
-                const int e = k * 64 + lane;
-                const bool asc = (e & SIZE) == 0 || SIZE == 64 * EPL;
+            static_for<0, EPL>([&](auto ck) {
+                constexpr int k = decltype(ck)::value;
                 if constexpr (J < 64) {
+                    // One compare and one select per exchange: a lane keeps its own value where "mine is smaller" agrees
+                    // with "this position takes the smaller one".  Which positions do is a constant of the step, so the
+                    // two lane masks are combined on the scalar unit (asm: the compiler would rebuild the constant mask
+                    // from the lane index, two vector instructions per step).
                     const float o = xor_lane<J>(v[k]);
-                    const bool lower = (lane & J) == 0;
-                    v[k] = (lower == asc) ? fminf(v[k], o) : fmaxf(v[k], o);
+                    constexpr unsigned long long TAKES_MIN = bitonic_min_lanes(SIZE, J, k, 64 * EPL);
+                    unsigned long long mine_smaller;
+                    asm("v_cmp_lt_f32 %0, %1, %2" : "=s"(mine_smaller) : "v"(v[k]), "v"(o));
+                    const unsigned long long keep = ~(mine_smaller ^ TAKES_MIN);
+                    // (the wait states a DPP read of a freshly written register needs: the compiler inserts them only
+                    // behind instructions it knows, and the next exchange may read this register through DPP)
+                    asm("v_cndmask_b32 %0, %1, %2, %3\n\ts_nop 1" : "=v"(v[k]) : "v"(o), "v"(v[k]), "s"(keep));
                 } else {
                     constexpr int KJ = J / 64;
-                    if ((k & KJ) == 0) {   // handle the pair (k, k + KJ) once
+                    if constexpr ((k & KJ) == 0) {   // handle the pair (k, k + KJ) once: every lane the same direction
+                        constexpr bool asc = ((k * 64) & SIZE) == 0 || SIZE == 64 * EPL;
                         const float lo = fminf(v[k], v[k ^ KJ]), hi = fmaxf(v[k], v[k ^ KJ]);
                         v[k] = asc ? lo : hi;
                         v[k ^ KJ] = asc ? hi : lo;
                     }
                 }
-            }
+            });
         });
     });
 }
@@ -254,21 +284,46 @@ __device__ __forceinline__ int count_below(const float* a, int n, int top, float
     return lo;
 }
 __device__ __forceinline__ int pow2_floor(int n) { return 1 << (31 - __builtin_clz(n)); }
+// The same count for a length known at compile time, 2^k or 2^k - 1: the classic halving search over 2^k - 1 entries
+// needs no bounds checks (k steps of read, compare, add), and the entry a power of two has on top counts only when all
+// the others did.
+template <bool LE, int N>
+__device__ __forceinline__ int count_below_fixed(const float* a, float v) {
+    constexpr bool POW2 = (N & (N - 1)) == 0;
+    constexpr int M = POW2 ? N - 1 : N;   // 2^k - 1
+    static_assert(((M + 1) & M) == 0, "a length of 2^k or 2^k - 1");
+    int lo = 0;
+#pragma unroll
+    for (int step = (M + 1) / 2; step >= 1; step >>= 1) {
+        const float t = a[lo + step - 1];
+        if (LE ? t <= v : t < v) lo += step;
+    }
+    if constexpr (POW2) {
+        const float t = a[N - 1];
+        if (lo == M && (LE ? t <= v : t < v)) lo = N;
+    }
+    return lo;
+}
+
 
 // NC_MAX: the coarse depths a wave's LDS arrays hold (128 or PDF_MAX_NC).  The kernel lives on its LDS round trips
 // (scan, three rounds of binary searches): with arrays sized for 256 + 1024 depths four workgroups fit a CU, sized for
 // the usual 64 + 128 eight do, the most its waves allow.
-template <int EPL, int NC_MAX>
-__global__ __launch_bounds__(PDF_WAVES * 64, (EPL <= 2 && NC_MAX <= 128) ? 8 : 1) void pdf_sample_kernel(
+// NC_FIX, NF_FIX: the shape when it is known at compile time (64 coarse + 128 fine, the reference configuration: every
+// loop bound and search depth is then a constant), 0 for a shape taken from the arguments.
+template <int EPL, int NC_MAX, int NC_FIX = 0, int NF_FIX = 0>
+__global__ __launch_bounds__(PDF_WAVES * 64, NC_FIX ? 8 : (EPL <= 2 && NC_MAX <= 128) ? 6 : 1) void pdf_sample_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z,
-    const float* __restrict__ weights, const float* __restrict__ u, int64_t R, int Nc, int Nf,
+    const float* __restrict__ weights, const float* __restrict__ u, int64_t R, int Nc_arg, int Nf_arg,
     float* __restrict__ z_fine, int32_t* __restrict__ idx_out, float* __restrict__ z_all, float* __restrict__ pts) {
+    const int Nc = NC_FIX ? NC_FIX : Nc_arg, Nf = NF_FIX ? NF_FIX : Nf_arg;
     __shared__ float s_scan[PDF_WAVES][2][NC_MAX];
     __shared__ float s_bins[PDF_WAVES][NC_MAX];
     __shared__ float s_zc[PDF_WAVES][NC_MAX];
     __shared__ float s_fine[PDF_WAVES][64 * EPL];
     __shared__ float s_sorted[PDF_WAVES][64 * EPL + NC_MAX];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index as a scalar: every per-ray address below is then formed on the scalar unit
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * PDF_WAVES + wv;
     if (ray >= R) return;   // whole wave
     const float* zr = z + ray * Nc;
@@ -276,6 +331,16 @@ __global__ __launch_bounds__(PDF_WAVES * 64, (EPL <= 2 && NC_MAX <= 128) ? 8 : 1
     const int nb = Nc - 1;  // bins and cdf entries
     const int nw = Nc - 2;  // interior weights
 
+    // every global load of the wave goes out now: issued where they are used, the uniforms and the ray would each add
+    // a round trip to memory to a chain that already waits for the depths and weights
+    float uu[EPL], ray_o[3], ray_d[3];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) uu[k] = k * 64 + lane < Nf ? u[ray * Nf + k * 64 + lane] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        ray_o[k] = pts ? rays_o[3 * ray + k] : 0.0f;
+        ray_d[k] = pts ? rays_d[3 * ray + k] : 0.0f;
+    }
     for (int k = lane; k < Nc; k += 64) s_zc[wv][k] = zr[k];
     float* cdf;
     if (nb <= 64) {
@@ -321,14 +386,16 @@ __global__ __launch_bounds__(PDF_WAVES * 64, (EPL <= 2 && NC_MAX <= 128) ? 8 : 1
         const int f = k * 64 + lane;
         zf[k] = __builtin_inff();   // padding sorts to the end
         if (f < Nf) {
-            const float uu = u[ray * Nf + f];
-            const int lo = count_below<true>(cdf, nb, top_nb, uu);   // first entry with cdf > uu
+            const float uk = uu[k];
+            int lo;   // first entry with cdf > the uniform
+            if constexpr (NC_FIX != 0) lo = count_below_fixed<true, NC_FIX - 1>(cdf, uk);
+            else lo = count_below<true>(cdf, nb, top_nb, uk);
             const int below = max(lo - 1, 0), above = min(lo, nb - 1);
             const float c_lo = cdf[below], c_hi = cdf[above];
             const float b_lo = s_bins[wv][below], b_hi = s_bins[wv][above];
             float denom = c_hi - c_lo;
             if (denom < 1e-5f) denom = 1.0f;
-            const float t = (uu - c_lo) / denom;
+            const float t = (uk - c_lo) / denom;
             zf[k] = b_lo + t * (b_hi - b_lo);
             if (z_fine) z_fine[ray * Nf + f] = zf[k];
             if (idx_out) idx_out[ray * Nf + f] = lo;
@@ -340,7 +407,7 @@ __global__ __launch_bounds__(PDF_WAVES * 64, (EPL <= 2 && NC_MAX <= 128) ? 8 : 1
     bool in_order = true;
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-        float next = __shfl_down(zf[k], 1, 64);
+        float next = dpp_move<DPP_WAVE_SHL1>(0.0f, zf[k]);   // lane i reads lane i + 1 (lane 63 is set below)
         if (lane == 63) next = k + 1 < EPL ? lane_value(zf[k + 1 < EPL ? k + 1 : k], 0) : __builtin_inff();
         in_order = in_order && zf[k] <= next;   // false for a NaN: the sort decides
     }
@@ -351,23 +418,26 @@ __global__ __launch_bounds__(PDF_WAVES * 64, (EPL <= 2 && NC_MAX <= 128) ? 8 : 1
     const int na = Nc + Nf;
     for (int i = lane; i < Nc; i += 64) {   // coarse depth i: fine depths strictly below it come first
         const float v = s_zc[wv][i];
-        s_sorted[wv][i + count_below<false>(s_fine[wv], Nf, top_nf, v)] = v;
+        int below_it;
+        if constexpr (NF_FIX != 0) below_it = count_below_fixed<false, NF_FIX>(s_fine[wv], v);
+        else below_it = count_below<false>(s_fine[wv], Nf, top_nf, v);
+        s_sorted[wv][i + below_it] = v;
     }
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {         // fine depth e: coarse depths up to and including it come first
         const int e = k * 64 + lane;
-        if (e < Nf) s_sorted[wv][e + count_below<true>(s_zc[wv], Nc, top_nc, zf[k])] = zf[k];
+        if (e < Nf) {
+            int up_to;
+            if constexpr (NC_FIX != 0) up_to = count_below_fixed<true, NC_FIX>(s_zc[wv], zf[k]);
+            else up_to = count_below<true>(s_zc[wv], Nc, top_nc, zf[k]);
+            s_sorted[wv][e + up_to] = zf[k];
+        }
     }
     wave_lds_sync();
     if (z_all)
         for (int i = lane; i < na; i += 64) z_all[ray * na + i] = s_sorted[wv][i];
     if (pts) {
-        float o[3], d[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            o[k] = rays_o[3 * ray + k];
-            d[k] = rays_d[3 * ray + k];
-        }
+        const float (&o)[3] = ray_o, (&d)[3] = ray_d;
         // a lane per sample, 12 contiguous bytes each: 64 lanes store 768 contiguous bytes per instruction
         float* out = pts + ray * na * 3;
         for (int smp = lane; smp < na; smp += 64) {
@@ -491,7 +561,10 @@ extern "C" int nerf_pdf_sample(const float* rays_o, const float* rays_d, const f
             hipLaunchKernelGGL((pdf_sample_kernel<EPL, PDF_MAX_NC>), grid, block, 0, (hipStream_t)stream, rays_o, rays_d, z,   \
                                weights, u, R, Nc, Nf, z_fine, idx, z_all, pts);                                              \
     } while (0)
-    if (Nf <= 64) PDF_LAUNCH(1);
+    if (Nc == 64 && Nf == 128)
+        hipLaunchKernelGGL((pdf_sample_kernel<2, 128, 64, 128>), grid, block, 0, (hipStream_t)stream, rays_o, rays_d, z, weights, u,
+                           R, Nc, Nf, z_fine, idx, z_all, pts);
+    else if (Nf <= 64) PDF_LAUNCH(1);
     else if (Nf <= 128) PDF_LAUNCH(2);
     else if (Nf <= 256) PDF_LAUNCH(4);
     else if (Nf <= 512) PDF_LAUNCH(8);
